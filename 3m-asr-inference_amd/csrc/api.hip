@@ -1,0 +1,183 @@
+// C-ABI entry points of libm3asr_hip.so that are thin wrappers over the kernel launchers
+// (include/m3asr.h documents which reference interface each one replaces).
+#include <string.h>
+
+#include "../../include/m3asr.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace m3 {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// workspace layout of the fused FMoE op (all sections 256-B aligned, as kAlignment in
+// the reference's common/common.h:43)
+struct MoeWorkspace {
+  int32_t* mapping;
+  int32_t* acc;
+  int32_t* pos;
+  float* slab;
+  size_t bytes;
+};
+MoeWorkspace carve_moe_workspace(void* base, int S, int E, int D, int F) {
+  MoeWorkspace w;
+  size_t off = 0;
+  char* p = (char*)base;
+  w.mapping = (int32_t*)(p + off); off += align_up((size_t)S * 4, 256);
+  w.acc = (int32_t*)(p + off);     off += align_up((size_t)(E + 1) * 4, 256);
+  w.pos = (int32_t*)(p + off);     off += align_up((size_t)S * 4, 256);
+  w.slab = (float*)(p + off);      off += align_up(expert_ffn_slab_bytes(S, D, F), 256);
+  w.bytes = off;
+  return w;
+}
+
+int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
+                   float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  M3_REQUIRE(S >= 0 && E > 0 && D > 0 && F > 0, "fmoe_expert: bad sizes S=%d E=%d D=%d F=%d", S, E, D, F);
+  if (S == 0) return 0;
+  MoeWorkspace w = carve_moe_workspace(ws, S, E, D, F);
+  M3_REQUIRE(ws != nullptr && ws_bytes >= w.bytes, "fmoe_expert: workspace %zu bytes < required %zu", ws_bytes,
+             w.bytes);
+  int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
+  if (rc) return rc;
+  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, w.slab, stream);
+  if (rc) return rc;
+  return launch_moe_combine(w.slab, F / kExpertSlice, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma,
+                            ln_beta, ln_eps, y, S, D, stream);
+}
+
+}  // namespace m3
+
+using namespace m3;
+
+extern "C" {
+
+int m3_abi_version(void) { return M3ASR_ABI_VERSION; }
+const char* m3_last_error(void) { return m3::last_error(); }
+
+int m3_moe_scatter_mapping(const int32_t* gate_idx, int S, int num_expert, int32_t* mapping, int32_t* acc_histogram,
+                           int32_t* pos, m3_stream stream) {
+  M3_REQUIRE(gate_idx && mapping && acc_histogram, "moe_scatter_mapping: null pointer");
+  return launch_moe_index(gate_idx, S, num_expert, mapping, acc_histogram, pos, (hipStream_t)stream);
+}
+int m3_moe_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, m3_stream stream) {
+  return launch_local_scatter(x, mapping, S, row_bytes, out, (hipStream_t)stream);
+}
+int m3_moe_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, m3_stream stream) {
+  return launch_local_gather(buf, mapping, S, row_bytes, out, (hipStream_t)stream);
+}
+size_t m3_moe_expert_workspace_size(int S, int num_expert, int idim, int hidden_units) {
+  if (S <= 0 || hidden_units % kExpertSlice) return 0;
+  return carve_moe_workspace(nullptr, S, num_expert, idim, hidden_units).bytes;
+}
+int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
+                      const float* b2, int S, int num_expert, int idim, int hidden_units, const float* gate_value,
+                      const float* resid, float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                      float* y, void* workspace, size_t workspace_bytes, m3_stream stream) {
+  return moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, S, num_expert, idim, hidden_units, gate_value, resid, alpha,
+                        ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
+                    int32_t* idx, float* value, m3_stream stream) {
+  return launch_softmax_top1(logits, ld, len, rows_per_batch, S, width, idx, value, (hipStream_t)stream);
+}
+
+int m3_linear(const m3_linear_desc* d, m3_stream stream) {
+  M3_REQUIRE(d != nullptr, "linear: null descriptor");
+  GemmParams p;
+  p.A = d->a; p.lda = d->lda;
+  p.A2 = d->a2; p.lda2 = d->lda2; p.K1 = d->k1;
+  p.mode = d->a2 ? GEMM_A_CONCAT2 : GEMM_A_PLAIN;
+  p.W = d->w; p.bias = d->bias; p.Y = d->y; p.ldy = d->ldy;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
+  p.row_len = d->len; p.rows_per_batch = d->rows_per_batch; p.mask_in = d->mask_in; p.mask_out = d->mask_out;
+  p.act = d->act; p.alpha = d->alpha; p.resid = d->resid; p.ldr = d->ldr;
+  return launch_gemm_f32(p, (hipStream_t)stream);
+}
+
+int m3_layer_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int dim,
+                  m3_stream stream) {
+  return launch_layernorm(x, gamma, beta, eps, y, rows, dim, (hipStream_t)stream);
+}
+int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
+                        const int32_t* len, int B, int T, int H, int dk, float scale, float* out, int ldo,
+                        m3_stream stream) {
+  return launch_relpos_attention(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo,
+                                 (hipStream_t)stream);
+}
+int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
+                      float eps, int B, int T, int D, int K, float* out, m3_stream stream) {
+  return launch_dwconv_ln_silu(z, w_kc, bias, gamma, beta, eps, B, T, D, K, out, (hipStream_t)stream);
+}
+int m3_subsample_conv1(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
+                       float* out, m3_stream stream) {
+  return launch_conv1_relu(feat, w9c, bias, B, T, idim, C, out, (hipStream_t)stream);
+}
+int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, float* out,
+                       m3_stream stream) {
+  M3_REQUIRE(T1 >= 3 && F1 >= 3, "subsample_conv2: input (%d,%d) smaller than the kernel", T1, F1);
+  GemmParams p;
+  p.mode = GEMM_A_CONV3X3S2;
+  p.A = in; p.lda = 4;
+  p.conv_T1 = T1; p.conv_F1 = F1; p.conv_T2 = (T1 - 3) / 2 + 1; p.conv_F2 = (F1 - 3) / 2 + 1; p.conv_C = C;
+  p.W = w; p.bias = bias; p.Y = out; p.ldy = C;
+  p.M = B * p.conv_T2 * p.conv_F2; p.N = C; p.K = 9 * C;
+  p.act = ACT_RELU;
+  return launch_gemm_f32(p, (hipStream_t)stream);
+}
+
+int m3_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
+                          float* out, m3_stream stream) {
+  return launch_att_masked_softmax(scores, len, B, H, T1, T2, scale, out, (hipStream_t)stream);
+}
+int m3_masked_fill(const float* x, const int32_t* len, int B, int C, int T, float fill, float* y, m3_stream stream) {
+  return launch_masked_fill(x, len, B, C, T, fill, y, (hipStream_t)stream);
+}
+int m3_glu(const float* x, int outer, int C, int inner, float* y, m3_stream stream) {
+  return launch_glu(x, outer, C, inner, y, (hipStream_t)stream);
+}
+int m3_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, int stride, int32_t* len_out,
+                          m3_stream stream) {
+  return launch_mask_conv2d_sample(len_in, B, left_padding, stride, len_out, (hipStream_t)stream);
+}
+int m3_scale(const float* x, float scale, float* y, size_t n, m3_stream stream) {
+  return launch_scale(x, scale, y, n, (hipStream_t)stream);
+}
+int m3_unary(const float* x, float* y, size_t n, int act, m3_stream stream) {
+  return launch_unary(x, y, n, act, (hipStream_t)stream);
+}
+int m3_binary(const float* a, const float* b, float* y, const int64_t* shape, const int64_t* strides_a,
+              const int64_t* strides_b, int ndim, int op, m3_stream stream) {
+  return launch_binary_bcast(a, b, y, shape, strides_a, strides_b, ndim, op, (hipStream_t)stream);
+}
+int m3_permute(const float* x, float* y, const int64_t* out_shape, const int64_t* in_strides, int ndim,
+               m3_stream stream) {
+  return launch_permute(x, y, out_shape, in_strides, ndim, (hipStream_t)stream);
+}
+int m3_concat_last(const float* a, int da, const float* b, int db, float* y, size_t rows, m3_stream stream) {
+  return launch_concat_last(a, da, b, db, y, rows, (hipStream_t)stream);
+}
+int m3_softmax(const float* x, float* y, size_t rows, int n, m3_stream stream) {
+  return launch_softmax_lastdim(x, y, rows, n, (hipStream_t)stream);
+}
+int m3_batched_matmul(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t stride_a,
+                      int64_t stride_b, int transpose_b, m3_stream stream) {
+  return launch_bmm(a, b, c, batch, M, N, K, stride_a, stride_b, transpose_b, (hipStream_t)stream);
+}
+int m3_depthwise_conv1d(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad,
+                        float* y, m3_stream stream) {
+  return launch_depthwise_conv1d_nct(x, w, bias, B, C, T, K, pad, y, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Fused relative-position multi-head attention (flash-style, fp32 MFMA 16x16x4).
+//
+// Replaces the layer chain emitted by RelPositionMultiHeadedAttention.forward
+// (trainer_3m_fix/layer/attention.py:320-384) + forward_attention_trt (:199-239):
+// 6 shuffles, 2 bias adds, q.k^T and q.p^T batched matmuls, add, AttMaskedSoftmax plugin
+// (att_masked_softmax_kernel.cu:224-272 / common.cuh:264-360), p.v matmul, transpose+reshape --
+// with the (B,h,T',T') score tensor never materialised:
+//   s_ij = ((q_i + u) . k_j + (q_i + v) . p_j) * scale          (NO rel_shift, as in the reference)
+//   a_ij = softmax_j(s_ij | j < len[b]),  a_ij = 0 for j >= len[b];   ctx_i = sum_j a_ij v_j
+// Inputs: qkv [B*T][ldq] = (q | k | v) rows from the fused QKV projection, p [T][ldp] = linear_pos(pos_emb)
+// (shared by the batch), pos_bias_u/v [h][dk].  Output ctx [B*T][ldo] with heads merged, i.e. the
+// "attn_transpose_and_reshape" shuffle is folded into the store.
+// One wave per (batch, head, 16-query tile); keys are walked in tiles of 16 with an online softmax;
+// the probability tile goes C-layout -> A-layout through a 1 KB LDS patch.
+#include "common.h"
+#include "kernels.h"
+
+namespace m3 {
+
+template <int DK>
+__global__ __launch_bounds__(64) void relpos_attention_kernel(const float* __restrict__ qkv, int ldq,
+                                                              const float* __restrict__ pmat, int ldp,
+                                                              const float* __restrict__ pos_u,
+                                                              const float* __restrict__ pos_v,
+                                                              const int32_t* __restrict__ row_len, int T, int D,
+                                                              float scale, float* __restrict__ out, int ldo) {
+  constexpr int KS = DK / 16;
+  __shared__ __attribute__((aligned(16))) float ps[16][20];
+  const int lane = threadIdx.x, col = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
+  const int len = min(row_len ? row_len[b] : T, T);
+  const size_t brow = (size_t)b * T;
+
+  const int qi = min(q0 + col, T - 1);
+  const float* qrow = qkv + (brow + qi) * ldq + h * DK + 4 * kq;
+  f32x4 qu[KS], qv[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const f32x4 q4 = ldg4(qrow + 16 * s);
+    qu[s] = q4 + ldg4(pos_u + h * DK + 16 * s + 4 * kq);
+    qv[s] = q4 + ldg4(pos_v + h * DK + 16 * s + 4 * kq);
+  }
+  f32x4 o[KS];
+#pragma unroll
+  for (int n = 0; n < KS; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m_run[r] = -INFINITY;
+    l_run[r] = 0.f;
+  }
+
+  for (int j0 = 0; j0 < len; j0 += 16) {
+    const int kj = min(j0 + col, T - 1);
+    const float* krow = qkv + (brow + kj) * ldq + D + h * DK + 4 * kq;
+    const float* prow = pmat + (size_t)kj * ldp + h * DK + 4 * kq;
+    f32x4 kb[KS], pb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kb[s] = ldg4(krow + 16 * s);
+      pb[s] = ldg4(prow + 16 * s);
+    }
+    // V fragments for this key tile: B[k = key 4kq+jj][n = channel 16n+col]
+    float vb[KS][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int vj = min(j0 + 4 * kq + jj, T - 1);
+      const float* vrow = qkv + (brow + vj) * ldq + 2 * D + h * DK + col;
+#pragma unroll
+      for (int n = 0; n < KS; ++n) vb[n][jj] = vrow[16 * n];
+    }
+    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc = mfma16(qu[s][j], kb[s][j], sc);
+        sc = mfma16(qv[s][j], pb[s][j], sc);
+      }
+    const bool valid = (j0 + col) < len;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sv = valid ? sc[r] * scale : -INFINITY;
+      const float m_new = fmaxf(m_run[r], group16_max(sv));
+      const float pexp = valid ? expf(sv - m_new) : 0.f;
+      const float corr = expf(m_run[r] - m_new);
+      l_run[r] = l_run[r] * corr + group16_sum(pexp);
+      m_run[r] = m_new;
+#pragma unroll
+      for (int n = 0; n < KS; ++n) o[n][r] *= corr;
+      ps[4 * kq + r][col] = pexp;
+    }
+    __syncthreads();
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[col][4 * kq]);
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < KS; ++n)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) o[n] = mfma16(pa[jj], vb[n][jj], o[n]);
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = q0 + 4 * kq + r;
+    if (i < T) {
+      const float inv = 1.f / l_run[r];
+#pragma unroll
+      for (int n = 0; n < KS; ++n) out[(brow + i) * ldo + h * DK + 16 * n + col] = o[n][r] * inv;
+    }
+  }
+}
+
+int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
+                            const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
+                            float* out, int ldo, hipStream_t stream) {
+  M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
+  M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0, "attention: row strides must be multiples of 4");
+  dim3 grid(cdiv(T, 16), H, B);
+  const int D = H * dk;
+#define M3_ATT_CASE(DK_)                                                                                   \
+  hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(64), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
+                     pos_v, row_len, T, D, scale, out, ldo)
+  switch (dk) {
+    case 16: M3_ATT_CASE(16); break;
+    case 32: M3_ATT_CASE(32); break;
+    case 64: M3_ATT_CASE(64); break;
+    case 128: M3_ATT_CASE(128); break;
+    default: M3_REQUIRE(false, "attention: d_k=%d unsupported (16/32/64/128)", dk);
+  }
+#undef M3_ATT_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace m3

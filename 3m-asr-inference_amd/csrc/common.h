@@ -1,0 +1,78 @@
+// Shared host/device helpers for libm3asr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+namespace m3 {
+
+// ---- error convention: int status + thread-local last-error string --------------------
+// (reference: status int from enqueue, CUDA errors only logged, common/common.h:26-38)
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define M3_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      m3::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+#define M3_REQUIRE(cond, ...)                  \
+  do {                                         \
+    if (!(cond)) {                             \
+      m3::set_error(__VA_ARGS__);              \
+      return -2;                               \
+    }                                          \
+  } while (0)
+
+#define M3_LAUNCH_CHECK() M3_CHECK_HIP(hipGetLastError())
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// 1-D grid of 256-thread blocks, capped (kernels grid-stride the rest)
+static inline unsigned grid1d(size_t n, size_t cap) {
+  size_t g = (n + 255) / 256;
+  return (unsigned)(g < cap ? g : cap);
+}
+
+// ---- device helpers ---------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reductions inside aligned 16-lane groups (rows of a 16x16 MFMA C tile)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// D = A(16x4) * B(4x16) + C, exact f32 (v_mfma_f32_16x16x4_f32).
+// lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c[r] = C[(l>>4)*4 + r][l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace m3

@@ -1,0 +1,557 @@
+// Whole-encoder engine: the native runtime that stands where the TensorRT engine stood.
+//
+// Reference: builder.py:36-98 builds a TensorRT plan from model.encoder(network_helper, feat, feat_len)
+// and infer.py:38-103 runs it with execute_v2.  The network being executed is
+//   Net.forward            trainer_3m_fix/model/conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234
+//   embed encoder          trainer_3m_fix/model/conformer_embed_domain_acc.py:149-181
+//   FmoeConformerLayer     trainer_3m_fix/layer/fmoe_transformer.py:72-170
+//   ConformerEncoderLayer  trainer_3m_fix/layer/transformer.py:179-275
+// Here the same network is an ordered list of fused kernel stages over caller-owned buffers, captured
+// once per (shape, buffers) into a hipGraph and replayed.  The residual stream x (S x D) is updated in
+// place by GEMM / combine epilogues; LayerNorms ride in GEMM prologues except where their output is a
+// tensor of its own (MoE input, block output).
+#include <math.h>
+#include <string.h>
+
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/m3asr.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace m3 {
+struct MoeWorkspace {
+  int32_t* mapping; int32_t* acc; int32_t* pos; float* slab; size_t bytes;
+};
+MoeWorkspace carve_moe_workspace(void* base, int S, int E, int D, int F);
+}  // namespace m3
+
+using namespace m3;
+
+namespace {
+
+struct Norm { const float* g = nullptr; const float* b = nullptr; };
+struct Lin { const float* w = nullptr; const float* b = nullptr; };
+
+struct BlockW {
+  Norm n_ffm, n_mha, n_conv, n_ff, n_final, n_cnn;
+  Lin mac1, mac2, qkv, pos, out, pw1, pw2, ff1, ff2;
+  const float* pos_u = nullptr; const float* pos_v = nullptr;
+  const float* dw_w = nullptr; const float* dw_b = nullptr;
+  Lin router;                       // w: [E_total][D + De]
+  const float *ew1 = nullptr, *eb1 = nullptr, *ew2 = nullptr, *eb2 = nullptr;
+};
+
+struct SubW { const float* c1w; const float* c1b; const float* c2w; const float* c2b; Lin out; };
+
+struct Stage {
+  std::string name;
+  std::function<int(hipStream_t)> run;
+};
+
+struct Buf { void* ptr; size_t bytes; };
+
+}  // namespace
+
+struct m3_engine {
+  m3_engine_config cfg;
+  std::unordered_map<std::string, m3_weight_entry> table;
+  std::vector<std::string> names;  // keeps c_str storage alive
+  SubW sub_e, sub_m;
+  std::vector<BlockW> eblocks, mblocks;
+  Norm e_after, m_after;
+  Lin out_linear;
+  const float* pe = nullptr;
+  int64_t pe_rows = 0;
+
+  // bound shape
+  int B = 0, T = 0, Tp = 0, S = 0;
+  const float* feat = nullptr; const int32_t* feat_len = nullptr; float* logits = nullptr;
+  void* ws = nullptr; size_t ws_bytes = 0;
+  std::vector<Stage> stages;
+  std::unordered_map<std::string, Buf> buffers;
+  int n_kernels = 0;
+
+  // graph cache (one entry: last bound shape)
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_valid = false;
+};
+
+namespace {
+
+bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const float** out) {
+  auto it = e->table.find(name);
+  if (it == e->table.end()) {
+    set_error("engine: weight '%s' missing from the plan", name.c_str());
+    return false;
+  }
+  if (numel >= 0 && it->second.numel != numel) {
+    set_error("engine: weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel,
+              (long long)numel);
+    return false;
+  }
+  *out = (const float*)it->second.data;
+  return true;
+}
+
+#define GET(dst, name, numel) \
+  if (!lookup(e, (name), (numel), &(dst))) return false
+
+bool load_norm(const m3_engine* e, const std::string& p, int d, Norm* n) {
+  GET(n->g, p + "weight", d);
+  GET(n->b, p + "bias", d);
+  return true;
+}
+bool load_lin(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n_in, bool bias, Lin* l) {
+  GET(l->w, p + "weight", n_out * n_in);
+  if (bias) GET(l->b, p + "bias", n_out);
+  return true;
+}
+
+bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, bool cnn_ln, bool moe, int De, BlockW* b) {
+  const m3_engine_config& c = e->cfg;
+  if (!load_norm(e, p + "norm_ff_macaron.", D, &b->n_ffm) || !load_norm(e, p + "norm_mha.", D, &b->n_mha) ||
+      !load_norm(e, p + "norm_conv.", D, &b->n_conv) || !load_norm(e, p + "norm_ff.", D, &b->n_ff) ||
+      !load_norm(e, p + "norm_final.", D, &b->n_final))
+    return false;
+  if (!load_lin(e, p + "feed_forward_macaron.w_1.", F, D, true, &b->mac1) ||
+      !load_lin(e, p + "feed_forward_macaron.w_2.", D, F, true, &b->mac2) ||
+      !load_lin(e, p + "self_attn.qkv.", 3 * D, D, true, &b->qkv) ||
+      !load_lin(e, p + "self_attn.linear_pos.", D, D, false, &b->pos) ||
+      !load_lin(e, p + "self_attn.linear_out.", D, D, true, &b->out) ||
+      !load_lin(e, p + "conv_module.pointwise_conv1.", 2 * D, D, true, &b->pw1) ||
+      !load_lin(e, p + "conv_module.pointwise_conv2.", D, D, true, &b->pw2))
+    return false;
+  GET(b->pos_u, p + "self_attn.pos_bias_u", D);
+  GET(b->pos_v, p + "self_attn.pos_bias_v", D);
+  GET(b->dw_w, p + "conv_module.depthwise_conv.weight_kc", (int64_t)K * D);
+  GET(b->dw_b, p + "conv_module.depthwise_conv.bias", D);
+  if (cnn_ln && !load_norm(e, p + "conv_module.norm.", D, &b->n_cnn)) return false;
+  if (!moe) {
+    if (!load_lin(e, p + "feed_forward.w_1.", F, D, true, &b->ff1) ||
+        !load_lin(e, p + "feed_forward.w_2.", D, F, true, &b->ff2))
+      return false;
+  } else {
+    const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
+    const int64_t Etot = (int64_t)c.num_experts * world;
+    GET(b->router.w, p + "feed_forward.router_weights_t", Etot * (D + De));
+    if (c.router_with_bias) GET(b->router.b, p + "feed_forward.router_bias", Etot);
+    const int64_t E = c.num_experts;
+    GET(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
+    GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
+    GET(b->ew2, p + "feed_forward.experts.w_2.weight", E * D * F);
+    GET(b->eb2, p + "feed_forward.experts.w_2.bias", E * D);
+  }
+  return true;
+}
+
+bool load_sub(const m3_engine* e, const std::string& p, int D, int idim, SubW* s) {
+  const int F2 = ((idim - 1) / 2 - 1) / 2;
+  GET(s->c1w, p + "conv.0.weight_9c", 9 * (int64_t)D);
+  GET(s->c1b, p + "conv.0.bias", D);
+  GET(s->c2w, p + "conv.2.weight_ohwi", 9 * (int64_t)D * D);
+  GET(s->c2b, p + "conv.2.bias", D);
+  return load_lin(e, p + "out.0.", D, (int64_t)D * F2, true, &s->out);
+}
+#undef GET
+
+inline int sub_len(int t) { return ((t - 3) / 2 + 1 - 3) / 2 + 1; }
+
+struct Carver {
+  char* base; size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T> T* take(size_t n) {
+    T* p = (T*)(base ? base + off : nullptr);
+    off += align_up(n * sizeof(T), 256);
+    return p;
+  }
+};
+
+// Buffer plan of one bound shape (identical code computes the size and the addresses).
+struct Plan {
+  int32_t* lens;
+  float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl;
+  int32_t* gate_idx; float* gate_val;   // [n_moe][S]
+  void* moe_ws; size_t moe_ws_bytes;
+  float* taps;                          // [n_blocks_total][S][D] when debug_taps
+  float* pfold;                         // [n_blocks_total][Tp][D] when fold_pos_proj
+  size_t bytes;
+};
+
+Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
+  Plan p;
+  Carver cv(base);
+  const int Tp = sub_len(T), S = B * Tp;
+  const int T1 = (T - 3) / 2 + 1, F1 = (c.input_dim - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  const int D = c.attention_dim > c.embed_dim ? c.attention_dim : c.embed_dim;
+  const int F = c.hidden_units > c.embed_linear_units ? c.hidden_units : c.embed_linear_units;
+  const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
+  const int Etot = c.num_experts * world;
+  p.lens = cv.take<int32_t>(B);
+  p.c1 = cv.take<float>((size_t)B * T1 * F1 * D);
+  p.c2 = cv.take<float>((size_t)S * F2 * D);
+  p.x = cv.take<float>((size_t)S * D);
+  p.emb = cv.take<float>((size_t)S * D);
+  p.h1 = cv.take<float>((size_t)S * F);
+  p.qkv = cv.take<float>((size_t)S * 3 * D);
+  p.pbuf = cv.take<float>((size_t)Tp * D);
+  p.ctx = cv.take<float>((size_t)S * D);
+  p.glu = cv.take<float>((size_t)S * D);
+  p.dw = cv.take<float>((size_t)S * D);
+  p.xn = cv.take<float>((size_t)S * D);
+  p.rl = cv.take<float>((size_t)S * Etot);
+  p.gate_idx = cv.take<int32_t>((size_t)c.num_blocks * S);
+  p.gate_val = cv.take<float>((size_t)c.num_blocks * S);
+  p.moe_ws_bytes = carve_moe_workspace(nullptr, S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
+  p.moe_ws = cv.take<char>(p.moe_ws_bytes * (size_t)(c.debug_taps ? c.num_blocks : 1));
+  p.taps = c.debug_taps ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * S * D) : nullptr;
+  p.pfold = c.fold_pos_proj ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * Tp * D) : nullptr;
+  p.bytes = cv.off;
+  return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+static void add_stage(m3_engine* e, const std::string& name, int kernels, std::function<int(hipStream_t)> fn) {
+  e->stages.push_back(Stage{name, std::move(fn)});
+  e->n_kernels += kernels;
+}
+
+static void add_gemm(m3_engine* e, const std::string& name, const GemmParams& p) {
+  add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); });
+}
+
+static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w, int D, const Plan& pl, float* xout) {
+  const m3_engine_config& c = e->cfg;
+  const int B = e->B, T = e->T;
+  const int T1 = (T - 3) / 2 + 1, F1 = (c.input_dim - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1;
+  const float* feat = e->feat;
+  float* c1 = pl.c1; float* c2 = pl.c2;
+  const int idim = c.input_dim;
+  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, B, T, idim, D, c1, s); });
+  GemmParams g;
+  g.mode = GEMM_A_CONV3X3S2; g.A = c1; g.lda = 4;
+  g.conv_T1 = T1; g.conv_F1 = F1; g.conv_T2 = T2; g.conv_F2 = F2; g.conv_C = D;
+  g.W = w.c2w; g.bias = w.c2b; g.Y = c2; g.ldy = D; g.M = B * T2 * F2; g.N = D; g.K = 9 * D; g.act = ACT_RELU;
+  add_gemm(e, pfx + "conv2", g);
+  // Linear(C*F2 -> D) on the (f, c)-ordered flatten, with the positional-encoding scale sqrt(D)
+  // (rel_positional_encoding_kernel.cu:62-69) folded into the epilogue.
+  GemmParams l;
+  l.A = c2; l.lda = F2 * D; l.W = w.out.w; l.bias = w.out.b; l.Y = xout; l.ldy = D;
+  l.M = B * T2; l.N = D; l.K = F2 * D; l.alpha = sqrtf((float)D);
+  add_gemm(e, pfx + "linear", l);
+}
+
+static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, int D, int F, int H, int K, bool cnn_ln,
+                        bool moe, int layer, int tap_index, const Plan& pl) {
+  const m3_engine_config& c = e->cfg;
+  const int B = e->B, Tp = e->Tp, S = e->S;
+  float* x = pl.x;
+  const int32_t* lens = pl.lens;
+  const float eps = 1e-12f;  // all block LayerNorms (fmoe_transformer.py:54-65)
+
+  {  // x += 0.5 * FFN_macaron(LN(x))
+    GemmParams g;
+    g.A = x; g.lda = D; g.W = w.mac1.w; g.bias = w.mac1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
+    g.ln_gamma = w.n_ffm.g; g.ln_beta = w.n_ffm.b; g.ln_eps = eps; g.act = ACT_SILU;
+    add_gemm(e, pfx + "ffn_macaron.w1", g);
+    GemmParams h;
+    h.A = pl.h1; h.lda = F; h.W = w.mac2.w; h.bias = w.mac2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
+    h.alpha = 0.5f; h.resid = x; h.ldr = D;
+    add_gemm(e, pfx + "ffn_macaron.w2", h);
+  }
+  {  // x += MHA(LN(x))
+    GemmParams g;
+    g.A = x; g.lda = D; g.W = w.qkv.w; g.bias = w.qkv.b; g.Y = pl.qkv; g.ldy = 3 * D; g.M = S; g.N = 3 * D; g.K = D;
+    g.ln_gamma = w.n_mha.g; g.ln_beta = w.n_mha.b; g.ln_eps = eps;
+    add_gemm(e, pfx + "att.qkv", g);
+    const float* pmat = pl.pbuf;
+    if (c.fold_pos_proj) {
+      pmat = pl.pfold + (size_t)tap_index * Tp * D;  // filled once at prepare()
+    } else {
+      GemmParams pp;
+      pp.A = e->pe; pp.lda = D; pp.W = w.pos.w; pp.Y = pl.pbuf; pp.ldy = D; pp.M = Tp; pp.N = D; pp.K = D;
+      add_gemm(e, pfx + "att.pos", pp);
+    }
+    const float* qkv = pl.qkv; float* ctx = pl.ctx;
+    const float* pu = w.pos_u; const float* pv = w.pos_v;
+    const int dk = D / H;
+    const float scale = 1.f / sqrtf((float)dk);
+    add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
+      return launch_relpos_attention(qkv, 3 * D, pmat, D, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s);
+    });
+    GemmParams o;
+    o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
+    o.resid = x; o.ldr = D;
+    add_gemm(e, pfx + "att.out", o);
+  }
+  {  // x += ConvModule(LN(x))
+    GemmParams g;
+    g.A = x; g.lda = D; g.W = w.pw1.w; g.bias = w.pw1.b; g.Y = pl.glu; g.ldy = D; g.M = S; g.N = 2 * D; g.K = D;
+    g.ln_gamma = w.n_conv.g; g.ln_beta = w.n_conv.b; g.ln_eps = eps; g.act = ACT_GLU;
+    g.row_len = lens; g.rows_per_batch = Tp; g.mask_in = 1;
+    add_gemm(e, pfx + "conv.pw1_glu", g);
+    const float* glu = pl.glu; float* dw = pl.dw;
+    const float* dww = w.dw_w; const float* dwb = w.dw_b;
+    const float* ng = cnn_ln ? w.n_cnn.g : nullptr; const float* nb = cnn_ln ? w.n_cnn.b : nullptr;
+    add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
+      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s);
+    });
+    GemmParams h;
+    h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
+    h.row_len = lens; h.rows_per_batch = Tp; h.mask_out = 1; h.resid = x; h.ldr = D;
+    add_gemm(e, pfx + "conv.pw2", h);
+  }
+  if (!moe) {  // x = LN_final(x + 0.5 * FFN(LN(x)))
+    GemmParams g;
+    g.A = x; g.lda = D; g.W = w.ff1.w; g.bias = w.ff1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
+    g.ln_gamma = w.n_ff.g; g.ln_beta = w.n_ff.b; g.ln_eps = eps; g.act = ACT_SILU;
+    add_gemm(e, pfx + "ffn.w1", g);
+    GemmParams h;
+    h.A = pl.h1; h.lda = F; h.W = w.ff2.w; h.bias = w.ff2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
+    h.alpha = 0.5f; h.resid = x; h.ldr = D;
+    add_gemm(e, pfx + "ffn.w2", h);
+    const float* fg = w.n_final.g; const float* fb = w.n_final.b;
+    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s); });
+  } else {  // x = LN_final(x + 0.5 * gate * Expert_g(LN(x)))     (positionwise_feed_forward.py:209-265)
+    const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
+    const int Etot = c.num_experts * world, E = c.num_experts, De = c.embed_dim;
+    float* xn = pl.xn; float* rl = pl.rl;
+    int32_t* gidx = pl.gate_idx + (size_t)layer * S;
+    float* gval = pl.gate_val + (size_t)layer * S;
+    const float* ng = w.n_ff.g; const float* nb = w.n_ff.b;
+    GemmParams r;
+    r.mode = GEMM_A_CONCAT2; r.A = pl.emb; r.lda = De; r.K1 = De; r.A2 = xn; r.lda2 = D;
+    r.W = w.router.w; r.bias = w.router.b; r.Y = rl; r.ldy = Etot; r.M = S; r.N = Etot; r.K = De + D;
+    add_stage(e, pfx + "moe_ln", 1, [=](hipStream_t s) { return launch_layernorm(x, ng, nb, eps, xn, S, D, s); });
+    add_gemm(e, pfx + "moe_router", r);
+    add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
+      return launch_softmax_top1(rl, Etot, lens, Tp, S, Etot, gidx, gval, s);
+    });
+    void* mws = (char*)pl.moe_ws + (c.debug_taps ? (size_t)layer * pl.moe_ws_bytes : 0);
+    const MoeWorkspace mw = carve_moe_workspace(mws, S, E, D, F);
+    const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
+    const float* fg = w.n_final.g; const float* fb = w.n_final.b;
+    const float* gv = c.keep_expert_output ? nullptr : gval;
+    // the three "moe_local" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
+    add_stage(e, pfx + "moe_local.index", 1, [=](hipStream_t s) {
+      return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
+    });
+    add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+      return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, mw.slab, s);
+    });
+    add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
+      return launch_moe_combine(mw.slab, F / kExpertSlice, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
+    });
+    const std::string b = pfx.substr(0, pfx.size() - 1);
+    e->buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
+    e->buffers[b + ".gate_value"] = Buf{gval, (size_t)S * 4};
+    e->buffers[b + ".mapping"] = Buf{mw.mapping, (size_t)S * 4};
+    e->buffers[b + ".acc_histogram"] = Buf{mw.acc, (size_t)(E + 1) * 4};
+  }
+  if (c.debug_taps) {
+    float* tap = pl.taps + (size_t)tap_index * S * D;
+    add_stage(e, pfx + "tap", 0, [=](hipStream_t s) {
+      M3_CHECK_HIP(hipMemcpyAsync(tap, x, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+      return 0;
+    });
+    e->buffers[pfx.substr(0, pfx.size() - 1) + ".out"] = Buf{tap, (size_t)S * D * 4};
+  }
+}
+
+extern "C" {
+
+int m3_engine_output_frames(int T) { return T >= 7 ? sub_len(T) : 0; }
+
+m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entry* table, int n_entries) {
+  if (!config || !table || n_entries <= 0) {
+    set_error("engine_create: null config / weight table");
+    return nullptr;
+  }
+  m3_engine* e = new m3_engine;
+  e->cfg = *config;
+  const m3_engine_config& c = e->cfg;
+  auto fail = [&](const char* msg) -> m3_engine* {
+    if (msg) set_error("%s", msg);
+    delete e;
+    return nullptr;
+  };
+  if (c.attention_dim % c.attention_heads || c.embed_dim % c.embed_heads) return fail("engine_create: dim % heads != 0");
+  if (c.attention_dim % 16 || c.embed_dim % 16 || c.hidden_units % 64 || c.embed_linear_units % 16)
+    return fail("engine_create: dims must be multiples of 16 (hidden_units of 64)");
+  if (c.embed_dim != c.attention_dim) return fail("engine_create: embed_dim != attention_dim is not supported");
+  e->names.reserve(n_entries);
+  for (int i = 0; i < n_entries; ++i) {
+    if (!table[i].name || !table[i].data) return fail("engine_create: null weight entry");
+    e->names.emplace_back(table[i].name);
+    m3_weight_entry w = table[i];
+    w.name = nullptr;
+    e->table[e->names.back()] = w;
+  }
+  const int D = c.attention_dim, De = c.embed_dim, K = c.cnn_module_kernel;
+  if (!load_sub(e, "embed.subsampling.", De, c.input_dim, &e->sub_e) || !load_sub(e, "subsampling.", D, c.input_dim, &e->sub_m))
+    return fail(nullptr);
+  if (!load_norm(e, "embed.after_norm.", De, &e->e_after) || !load_norm(e, "after_norm.", D, &e->m_after) ||
+      !load_lin(e, "out_linear.", c.output_dim, D, true, &e->out_linear))
+    return fail(nullptr);
+  {
+    auto it = e->table.find("pe");
+    if (it == e->table.end() || it->second.numel % D) return fail("engine_create: positional table 'pe' missing");
+    e->pe = (const float*)it->second.data;
+    e->pe_rows = it->second.numel / D;
+  }
+  e->eblocks.resize(c.embed_blocks);
+  for (int i = 0; i < c.embed_blocks; ++i)
+    if (!load_block(e, "embed.blocks." + std::to_string(i) + ".", De, c.embed_linear_units, K, c.embed_cnn_layer_norm,
+                    false, De, &e->eblocks[i]))
+      return fail(nullptr);
+  e->mblocks.resize(c.num_blocks);
+  for (int i = 0; i < c.num_blocks; ++i)
+    if (!load_block(e, "blocks." + std::to_string(i) + ".", D, c.hidden_units, K, c.cnn_layer_norm, true, De,
+                    &e->mblocks[i]))
+      return fail(nullptr);
+  return e;
+}
+
+void m3_engine_destroy(m3_engine* engine) {
+  if (!engine) return;
+  if (engine->graph_exec) hipGraphExecDestroy(engine->graph_exec);
+  delete engine;
+}
+
+size_t m3_engine_workspace_size(const m3_engine* engine, int B, int T) {
+  if (!engine || B <= 0 || T < 7) return 0;
+  return make_plan(engine->cfg, nullptr, B, T).bytes;
+}
+
+int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                      void* workspace, size_t workspace_bytes) {
+  M3_REQUIRE(e && feat && feat_len && logits && workspace, "engine_prepare: null argument");
+  M3_REQUIRE(B > 0 && T >= 7, "engine_prepare: need B > 0 and T >= 7 frames (got B=%d T=%d)", B, T);
+  const m3_engine_config& c = e->cfg;
+  const int Tp = sub_len(T);
+  M3_REQUIRE(Tp < e->pe_rows, "engine_prepare: T'=%d exceeds the positional table (%lld rows)", Tp,
+             (long long)e->pe_rows);  // rel_positional_encoding_plugin.cpp:139-142
+  if (int rc = init_expert_ffn_kernels()) return rc;
+  const Plan pl = make_plan(c, workspace, B, T);
+  M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
+  e->B = B; e->T = T; e->Tp = Tp; e->S = B * Tp;
+  e->feat = feat; e->feat_len = feat_len; e->logits = logits; e->ws = workspace; e->ws_bytes = workspace_bytes;
+  e->stages.clear(); e->buffers.clear(); e->n_kernels = 0; e->graph_valid = false;
+  const int S = e->S, D = c.attention_dim, De = c.embed_dim;
+
+  // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
+  {
+    int32_t* lens = pl.lens;
+    add_stage(e, "lens", 2, [=](hipStream_t s) {
+      int rc = launch_mask_conv2d_sample(feat_len, B, 2, 2, lens, s);
+      if (rc) return rc;
+      return launch_mask_conv2d_sample(lens, B, 2, 2, lens, s);
+    });
+  }
+  // ---- embed encoder (conformer_embed_domain_acc.py:149-181) ----
+  build_subsample(e, "embed.subsample.", e->sub_e, De, pl, pl.x);
+  for (int i = 0; i < c.embed_blocks; ++i)
+    build_block(e, "embed.blocks." + std::to_string(i) + ".", e->eblocks[i], De, c.embed_linear_units, c.embed_heads,
+                c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, pl);
+  {
+    float* x = pl.x; float* emb = pl.emb;
+    const float* g = e->e_after.g; const float* b = e->e_after.b;
+    add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); });
+  }
+  // ---- main MoE encoder (conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) ----
+  build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);
+  for (int i = 0; i < c.num_blocks; ++i)
+    build_block(e, "blocks." + std::to_string(i) + ".", e->mblocks[i], D, c.hidden_units, c.attention_heads,
+                c.cnn_module_kernel, c.cnn_layer_norm, true, i, c.embed_blocks + i, pl);
+  {
+    GemmParams g;
+    g.A = pl.x; g.lda = D; g.W = e->out_linear.w; g.bias = e->out_linear.b; g.Y = logits; g.ldy = c.output_dim;
+    g.M = S; g.N = c.output_dim; g.K = D;
+    g.ln_gamma = e->m_after.g; g.ln_beta = e->m_after.b; g.ln_eps = 1e-12f;
+    add_gemm(e, "logits", g);
+  }
+  e->buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
+  e->buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
+  e->buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
+  e->buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
+  e->buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
+
+  // input-independent p = linear_pos(pe[:T']) per block, computed once per bound shape
+  if (c.fold_pos_proj) {
+    hipStream_t s = nullptr;
+    for (int i = 0; i < c.embed_blocks + c.num_blocks; ++i) {
+      const BlockW& w = i < c.embed_blocks ? e->eblocks[i] : e->mblocks[i - c.embed_blocks];
+      GemmParams pp;
+      pp.A = e->pe; pp.lda = D; pp.W = w.pos.w; pp.Y = pl.pfold + (size_t)i * Tp * D; pp.ldy = D; pp.M = Tp; pp.N = D; pp.K = D;
+      if (int rc = launch_gemm_f32(pp, s)) return rc;
+    }
+    M3_CHECK_HIP(hipStreamSynchronize(s));
+  }
+  return (int)e->stages.size();
+}
+
+int m3_engine_num_stages(const m3_engine* engine) { return engine ? (int)engine->stages.size() : 0; }
+const char* m3_engine_stage_name(const m3_engine* engine, int index) {
+  if (!engine || index < 0 || index >= (int)engine->stages.size()) return nullptr;
+  return engine->stages[index].name.c_str();
+}
+int m3_engine_num_kernels(const m3_engine* engine) { return engine ? engine->n_kernels : 0; }
+
+int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream stream) {
+  M3_REQUIRE(engine && !engine->stages.empty(), "engine_run: engine not prepared");
+  M3_REQUIRE(first_stage >= 0 && last_stage <= (int)engine->stages.size() && first_stage <= last_stage,
+             "engine_run: bad stage range [%d,%d)", first_stage, last_stage);
+  for (int i = first_stage; i < last_stage; ++i)
+    if (int rc = engine->stages[i].run((hipStream_t)stream)) return rc;
+  return 0;
+}
+
+int m3_engine_buffer(const m3_engine* engine, const char* name, void** ptr, size_t* bytes) {
+  M3_REQUIRE(engine && name && ptr && bytes, "engine_buffer: null argument");
+  auto it = engine->buffers.find(name);
+  M3_REQUIRE(it != engine->buffers.end(), "engine_buffer: no buffer named '%s' for the bound shape", name);
+  *ptr = it->second.ptr;
+  *bytes = it->second.bytes;
+  return 0;
+}
+
+int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                      void* workspace, size_t workspace_bytes, int use_graph, m3_stream stream_) {
+  M3_REQUIRE(e != nullptr, "engine_forward: null engine");
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool rebound = e->stages.empty() || e->B != B || e->T != T || e->feat != feat || e->feat_len != feat_len ||
+                       e->logits != logits || e->ws != workspace || e->ws_bytes != workspace_bytes;
+  if (rebound) {
+    int rc = m3_engine_prepare(e, feat, feat_len, B, T, logits, workspace, workspace_bytes);
+    if (rc < 0) return rc;
+  }
+  if (!use_graph) return m3_engine_run(e, 0, (int)e->stages.size(), stream_);
+  if (!e->graph_valid) {
+    M3_REQUIRE(stream != nullptr, "engine_forward: graph capture needs a non-default stream");
+    if (e->graph_exec) {
+      hipGraphExecDestroy(e->graph_exec);
+      e->graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    M3_CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    int rc = m3_engine_run(e, 0, (int)e->stages.size(), stream_);
+    hipError_t ce = hipStreamEndCapture(stream, &graph);
+    if (rc) {
+      if (graph) hipGraphDestroy(graph);
+      return rc;
+    }
+    M3_CHECK_HIP(ce);
+    M3_CHECK_HIP(hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0));
+    M3_CHECK_HIP(hipGraphDestroy(graph));
+    e->graph_valid = true;
+  }
+  M3_CHECK_HIP(hipGraphLaunch(e->graph_exec, stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal launcher interface of libm3asr_hip.so (C++ side; the C-ABI lives in include/m3asr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m3 {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GLU = 3 };
+enum { GEMM_A_PLAIN = 0, GEMM_A_CONCAT2 = 1, GEMM_A_CONV3X3S2 = 2 };
+
+struct GemmParams {
+  // operands: Y[M,Nout] = epi( pro(A)[M,K] . W[N,K]^T )
+  const float* A = nullptr; int lda = 0;
+  const float* A2 = nullptr; int lda2 = 0; int K1 = 0;   // CONCAT2: k<K1 from A, else A2[k-K1]
+  const float* W = nullptr;                               // [N][K] row-major
+  const float* bias = nullptr;                            // [N] or null
+  float* Y = nullptr; int ldy = 0;
+  int M = 0, N = 0, K = 0;
+  int mode = GEMM_A_PLAIN;
+  // prologue
+  const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 0.f;
+  const int32_t* row_len = nullptr; int rows_per_batch = 0;  // frame t = row % rows_per_batch is padded if t >= row_len[row / rows_per_batch]
+  int mask_in = 0, mask_out = 0;
+  // implicit 3x3 stride-2 conv over a channel-last (B,T1,F1,C) input -> rows (b,t2,f2)
+  int conv_T1 = 0, conv_F1 = 0, conv_T2 = 0, conv_F2 = 0, conv_C = 0;
+  // epilogue
+  int act = ACT_NONE;
+  float alpha = 1.f;
+  const float* resid = nullptr; int ldr = 0;
+};
+int launch_gemm_f32(const GemmParams& p, hipStream_t stream);
+
+// ---- MoE indexing / scatter / gather (moe_index.hip) ----
+int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist,
+                     int32_t* pos, hipStream_t stream);
+int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
+int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
+
+// ---- grouped expert FFN (moe_expert.hip) ----
+constexpr int kExpertSlice = 64;  // hidden units per workgroup
+size_t expert_ffn_slab_bytes(int S, int D, int F);
+int init_expert_ffn_kernels();
+int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
+                          int D, int F, const float* w1, const float* b1, const float* w2, float* slab,
+                          hipStream_t stream);
+// out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
+int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
+                       const float* gate_value, const float* b2, const float* resid, float alpha,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
+                       hipStream_t stream);
+
+// ---- row-wise ops (rowops.hip) ----
+int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
+                     hipStream_t stream);
+int launch_softmax_top1(const float* logits, int ld, const int32_t* row_len, int rows_per_batch, int S, int E,
+                        int32_t* idx, float* value, hipStream_t stream);
+int launch_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
+                              float* out, hipStream_t stream);
+int launch_masked_fill(const float* x, const int32_t* len, int B, int C, int T, float fill, float* y,
+                       hipStream_t stream);
+int launch_glu(const float* x, int outer, int C, int inner, float* y, hipStream_t stream);
+int launch_scale(const float* x, float scale, float* y, size_t n, hipStream_t stream);
+int launch_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, int stride, int32_t* len_out,
+                              hipStream_t stream);
+int launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t stream);
+int launch_binary_bcast(const float* a, const float* b, float* y, const int64_t* shape, const int64_t* sa,
+                        const int64_t* sb, int nd, int op, hipStream_t stream);
+int launch_unary(const float* x, float* y, size_t n, int act, hipStream_t stream);
+int launch_permute(const float* x, float* y, const int64_t* out_shape, const int64_t* in_strides, int nd,
+                   hipStream_t stream);
+int launch_concat_last(const float* a, int da, const float* b, int db, float* y, size_t rows, hipStream_t stream);
+int launch_softmax_lastdim(const float* x, float* y, size_t rows, int n, hipStream_t stream);
+int launch_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t sa, int64_t sb,
+               int trans_b, hipStream_t stream);
+
+// ---- fused rel-pos attention (attention.hip) ----
+int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
+                            const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
+                            float* out, int ldo, hipStream_t stream);
+
+// ---- conv module / subsampling (conv.hip) ----
+int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
+                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream);
+int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
+                      float* out, hipStream_t stream);
+int launch_depthwise_conv1d_nct(const float* x, const float* w, const float* bias, int B, int C, int T, int K,
+                                int pad, float* y, hipStream_t stream);
+
+}  // namespace m3

@@ -1,0 +1,294 @@
+// Grouped 32-expert FFN  Y = SiLU(X W1[e]^T + b1[e]) W2[e]^T + b2[e]  for all experts in ONE launch.
+//
+// Replaces compute_fmoe_expert's host loop (TRTAPI++/plugin/fmoe_expert_plugin/fmoe_expert_plugin.cpp:36-142):
+// D2H copy of the histogram + stream sync (:75-78), <=4*E launches on 8 streams (cublasSgemm,
+// BiasSiluKernel, cublasSgemm, BiasKernel; fmoe_expert_kernel.cu:130-189) and 8 host syncs (:130).
+// Here the per-expert row ranges are read on the device from acc_hist, so there is no host
+// round trip and the op is graph-capturable.
+//
+// Work item = (expert e, 64-wide slice of the hidden dimension).  The workgroup
+//   1. gathers its expert's token rows x[pos[acc[e]+i]] into LDS (the local_scatter is fused away),
+//   2. phase 1: H[:, slice] = SiLU(X . W1[e][slice,:]^T + b1)   -- each wave owns 16 hidden units and
+//      streams their W1 rows (2 KB each) straight into VGPRs, A fragments come from LDS,
+//   3. keeps H in LDS, phase 2: Ypart = H[:, slice] . W2[e][:, slice]^T -- each wave owns D/4 output
+//      columns and streams the 256-B row pieces of W2,
+//   4. writes Ypart to slab[slice][sorted row][D]; moe_combine_kernel sums the F/64 slabs in a fixed
+//      order (bitwise reproducible, no float atomics), adds b2, applies gate * ff_scale, the
+//      residual and optionally the block's final LayerNorm, and un-permutes rows (local_gather).
+// Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32).  At B=1x206 (S=50, ~2 rows/expert) the launch is
+// pure weight streaming: 4.2 MB per touched expert, E*F/64 = 512 workgroups of 256 KB each.
+#include "common.h"
+#include "kernels.h"
+
+namespace m3 {
+
+template <int MT>
+__global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __restrict__ x, int ldx,
+                                                             const int32_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ acc_hist, int S, int D,
+                                                             int F, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1,
+                                                             const float* __restrict__ w2,
+                                                             float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int e = blockIdx.y, slice = blockIdx.x;
+  const int row_lo = acc_hist[e], row_hi = acc_hist[e + 1];
+  if (row_hi <= row_lo) return;  // empty expert: nothing streamed
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int xs_ld = D + 8;                   // +8 floats: conflict-free ds_read_b128 of A fragments
+  constexpr int hs_ld = kExpertSlice + 8;
+  float* xs = lds;                           // [16*MT][D+8]
+  float* hs = lds + 16 * MT * xs_ld;         // [16*MT][64+8]
+  const int f0 = slice * kExpertSlice;
+  const int ksteps1 = D >> 4;
+
+  const float* w1row = w1 + ((size_t)e * F + f0 + 16 * wave + col) * D + 4 * kq;
+  const float bias1 = b1[(size_t)e * F + f0 + 16 * wave + col];
+  const int nsub = D >> 4;                   // 16-column output tiles of phase 2
+
+  for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
+    const int nrows = min(16 * MT, row_hi - r0);
+
+    // W1 prefetch (first group) is issued before the X staging so HBM latency overlaps it
+    f32x4 wb[2][8];
+    auto load_w1 = [&](int g, int buf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int s = 8 * g + i;
+        if (s < ksteps1) wb[buf][i] = ldg4(w1row + (s << 4));
+      }
+    };
+    load_w1(0, 0);
+
+    // ---- gather token rows into LDS (fused local_scatter) ----
+    __syncthreads();  // previous row tile finished reading xs / hs
+    for (int i = wave; i < 16 * MT; i += 4) {
+      float* dst = xs + i * xs_ld;
+      if (i < nrows) {
+        const float* src = x + (size_t)pos[r0 + i] * ldx;
+        for (int c = lane * 4; c < D; c += 256) stg4(dst + c, ldg4(src + c));
+      } else {
+        for (int c = lane * 4; c < D; c += 256) stg4(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 1: H[:, f0+16w .. +16) over the full K = D ----
+    f32x4 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = (ksteps1 + 7) >> 3;
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load_w1(g + 1, 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int s = 8 * g + i;
+        if (s < ksteps1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + (16 * mt + col) * xs_ld + (s << 4) + 4 * kq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1[mt] = mfma16(a[j], wb[0][i][j], acc1[mt]);
+          }
+        }
+      }
+      if (g + 1 < ngroups) {
+        if (g + 2 < ngroups) load_w1(g + 2, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int s = 8 * (g + 1) + i;
+          if (s < ksteps1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(xs + (16 * mt + col) * xs_ld + (s << 4) + 4 * kq);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc1[mt] = mfma16(a[j], wb[1][i][j], acc1[mt]);
+            }
+          }
+        }
+      }
+    }
+
+    // first W2 tile of this wave is requested before the barrier
+    f32x4 w2b[2][4];
+    auto load_w2 = [&](int sub, int buf) {
+      if (sub < nsub) {
+        const float* p = w2 + ((size_t)e * D + 16 * sub + col) * F + f0 + 4 * kq;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) w2b[buf][st] = ldg4(p + 16 * st);
+      }
+    };
+    load_w2(wave, 0);
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        hs[(16 * mt + 4 * kq + r) * hs_ld + 16 * wave + col] = silu(acc1[mt][r] + bias1);
+    __syncthreads();
+
+    // ---- phase 2: Ypart[:, 16*sub .. +16) for sub = wave, wave+4, ..  (K = 64 hidden units) ----
+    f32x4 hfrag[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        hfrag[mt][st] = *reinterpret_cast<const f32x4*>(hs + (16 * mt + col) * hs_ld + 16 * st + 4 * kq);
+
+    float* slab_base = slab + ((size_t)slice * S + r0) * D;
+    auto tile2 = [&](int sub, int buf) {  // buf is a literal at every call site (static register index)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc2 = mfma16(hfrag[mt][st][j], w2b[buf][st][j], acc2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * kq + r;
+          if (i < nrows) slab_base[(size_t)i * D + 16 * sub + col] = acc2[r];
+        }
+      }
+    };
+    for (int sub = wave; sub < nsub; sub += 8) {
+      load_w2(sub + 4, 1);
+      tile2(sub, 0);
+      if (sub + 4 < nsub) {
+        load_w2(sub + 8, 0);
+        tile2(sub + 4, 1);
+      }
+    }
+  }
+}
+
+// Opt the big-tile variants into > 64 KB of dynamic LDS once (not a stream operation: must not
+// happen inside a hipGraph capture, so the engine calls this at prepare time).
+int init_expert_ffn_kernels() {
+  static bool done = false;
+  if (done) return 0;
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+  done = true;
+  return 0;
+}
+
+size_t expert_ffn_slab_bytes(int S, int D, int F) {
+  return (size_t)(F / kExpertSlice) * (size_t)S * (size_t)D * sizeof(float);
+}
+
+int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
+                          int F, const float* w1, const float* b1, const float* w2, float* slab,
+                          hipStream_t stream) {
+  M3_REQUIRE(S > 0 && E > 0, "expert_ffn: empty problem S=%d E=%d", S, E);
+  M3_REQUIRE((D & 15) == 0 && D <= 2048, "expert_ffn: idim=%d must be a multiple of 16 (<=2048)", D);
+  M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
+  M3_REQUIRE((ldx & 3) == 0, "expert_ffn: ldx=%d must be a multiple of 4", ldx);
+  // rows per tile: small batches keep LDS small (more workgroups per CU -> more bytes in flight)
+  const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
+  const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(float);
+  M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn: LDS tile of %zu bytes does not fit", lds_bytes);
+  dim3 grid(F / kExpertSlice, E);
+  if (int rc = init_expert_ffn_kernels()) return rc;
+#define M3_EXPERT_CASE(MT_)                                                                             \
+  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(256), lds_bytes, stream, x, ldx, pos,    \
+                     acc_hist, S, D, F, w1, b1, w2, slab)
+  if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
+#undef M3_EXPERT_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_k slab[k][mapping[s]])  (+ optional LayerNorm)
+// One wave per token row; NV = float4 per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restrict__ slab, int n_slices,
+                                                          const int32_t* __restrict__ mapping,
+                                                          const int32_t* __restrict__ gate_idx,
+                                                          const float* __restrict__ gate_value,
+                                                          const float* __restrict__ b2,
+                                                          const float* resid, float alpha,
+                                                          const float* __restrict__ ln_gamma,
+                                                          const float* __restrict__ ln_beta, float ln_eps,
+                                                          float* out, int S, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wave;
+  if (s >= S) return;
+  const int m = mapping[s];
+  const int g = gate_idx[s];
+  const float gate = (m >= 0) ? (gate_value ? gate_value[s] : 1.f) : 0.f;
+  f32x4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m >= 0) {
+        y = ldg4(b2 + (size_t)g * D + c);
+        for (int k = 0; k < n_slices; ++k) {
+          const f32x4 t = ldg4(slab + ((size_t)k * S + m) * D + c);
+          y += t;
+        }
+      }
+      y *= (alpha * gate);
+      if (resid) y += ldg4(resid + (size_t)s * D + c);
+      v[i] = y;
+      sum += (y[0] + y[1]) + (y[2] + y[3]);
+    }
+  }
+  if (ln_gamma) {
+    const float mean = wave_sum(sum) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + ln_eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+        const f32x4 ga = ldg4(ln_gamma + c), be = ldg4(ln_beta + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * ga[j] + be[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) stg4(out + (size_t)s * D + c, v[i]);
+  }
+}
+
+int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
+                       const float* gate_value, const float* b2, const float* resid, float alpha,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
+                       hipStream_t stream) {
+  M3_REQUIRE((D & 3) == 0 && D <= 2048, "moe_combine: D=%d must be a multiple of 4 (<=2048)", D);
+  if (S == 0) return 0;
+  const int nv = cdiv(D, 256);
+  dim3 grid(cdiv(S, 4));
+#define M3_COMBINE_CASE(NV_)                                                                              \
+  hipLaunchKernelGGL((moe_combine_kernel<NV_>), grid, dim3(256), 0, stream, slab, n_slices, mapping,     \
+                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D)
+  if (nv <= 1) M3_COMBINE_CASE(1); else if (nv <= 2) M3_COMBINE_CASE(2); else if (nv <= 4) M3_COMBINE_CASE(4); else M3_COMBINE_CASE(8);
+#undef M3_COMBINE_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace m3

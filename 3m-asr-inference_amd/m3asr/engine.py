@@ -1,0 +1,137 @@
+"""Python handle on the native encoder engine (m3_engine_* in include/m3asr.h).
+
+Plays the role of TensorRT's ICudaEngine + IExecutionContext in the reference
+(infer.py:27-103, TRTAPI++/python/trt_helper/infer_helper.py:37-161): weights live in device
+memory owned by this object (torch tensors), activations in a caller-visible workspace tensor, the
+forward is one C call that replays a hipGraph.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .config import EncoderConfig, subsampled_len
+from .plan import pack_weights
+
+
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps):
+    ec = _lib.EngineConfig()
+    ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
+    ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
+    ec.embed_dim, ec.embed_heads = cfg.embed_dim, cfg.embed_heads
+    ec.embed_linear_units, ec.embed_blocks = cfg.embed_linear_units, cfg.embed_blocks
+    ec.num_experts, ec.hidden_units = cfg.num_experts, cfg.hidden_units
+    ec.cnn_module_kernel = cfg.cnn_module_kernel
+    ec.cnn_layer_norm = int(cfg.cnn_module_norm == "layer_norm")
+    ec.embed_cnn_layer_norm = int(cfg.embed_cnn_module_norm == "layer_norm")
+    ec.router_with_bias, ec.keep_expert_output = int(cfg.router_with_bias), int(cfg.keep_expert_output)
+    ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
+    ec.fold_pos_proj, ec.debug_taps = int(fold_pos_proj), int(debug_taps)
+    return ec
+
+
+class Engine:
+    def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False):
+        """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors)."""
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.weights = {k: v.to(self.device, non_blocking=False).contiguous() for k, v in packed.items()}
+        names = list(self.weights)
+        table = (_lib.WeightEntry * len(names))()
+        self._keep = [n.encode() for n in names]
+        for i, n in enumerate(names):
+            table[i].name = self._keep[i]
+            table[i].data = self.weights[n].data_ptr()
+            table[i].numel = self.weights[n].numel()
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps)
+        self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
+        if not self.handle:
+            raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._ws = None
+        self._bound = None
+
+    @classmethod
+    def from_state_dict(cls, cfg, state_dict, **kw):
+        return cls(cfg, pack_weights(state_dict, cfg), **kw)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.m3_engine_destroy(h)
+
+    def weight_bytes(self):
+        return sum(v.numel() * 4 for v in self.weights.values())
+
+    def output_shape(self, B, T):
+        return (B, subsampled_len(T), self.cfg.output_dim)
+
+    def workspace_size(self, B, T):
+        return self.lib.m3_engine_workspace_size(self.handle, B, T)
+
+    def _workspace(self, B, T):
+        need = self.workspace_size(B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def bind(self, feat, feat_len, logits=None):
+        """Bind device buffers (feat (B,T,idim) f32, feat_len (1,B)/(B,) i32); returns logits tensor."""
+        assert feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
+        assert feat_len.is_cuda and feat_len.dtype == torch.int32 and feat_len.is_contiguous()
+        B, T, _ = feat.shape
+        if logits is None:
+            logits = torch.empty(self.output_shape(B, T), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, T)
+        n = self.lib.m3_engine_prepare(self.handle, feat.data_ptr(), feat_len.data_ptr(), B, T, logits.data_ptr(),
+                                       ws.data_ptr(), ws.numel())
+        if n < 0:
+            raise _lib.M3Error("m3_engine_prepare failed: " + _lib.last_error())
+        self._bound = (feat, feat_len, logits, ws, B, T)
+        return logits
+
+    def forward(self, feat=None, feat_len=None, logits=None, use_graph=True, stream=None):
+        """Enqueue one encoder forward on `stream` (default: the engine's own stream).  With no
+        arguments the last bound buffers are reused (steady-state replay)."""
+        if feat is not None:
+            b = self._bound
+            if b is None or b[0].data_ptr() != feat.data_ptr() or b[1].data_ptr() != feat_len.data_ptr() or \
+                    tuple(b[0].shape) != tuple(feat.shape) or (logits is not None and logits.data_ptr() != b[2].data_ptr()):
+                self.bind(feat, feat_len, logits)
+        feat, feat_len, logits, ws, B, T = self._bound
+        st = stream if stream is not None else self.stream
+        check(self.lib.m3_engine_forward(self.handle, feat.data_ptr(), feat_len.data_ptr(), B, T, logits.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), int(use_graph), C.c_void_p(st.cuda_stream)),
+              "m3_engine_forward")
+        return logits
+
+    def __call__(self, feat, feat_len):
+        """Synchronous convenience: waits for prior work on the current stream, runs, syncs."""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        out = self.forward(feat, feat_len, use_graph=False)
+        self.stream.synchronize()
+        return out
+
+    # ---- staged execution / taps ---------------------------------------------------------
+    def stage_names(self):
+        n = self.lib.m3_engine_num_stages(self.handle)
+        return [self.lib.m3_engine_stage_name(self.handle, i).decode() for i in range(n)]
+
+    def num_kernels(self):
+        return self.lib.m3_engine_num_kernels(self.handle)
+
+    def run_stages(self, first, last, stream=None):
+        st = stream if stream is not None else self.stream
+        check(self.lib.m3_engine_run(self.handle, first, last, C.c_void_p(st.cuda_stream)), "m3_engine_run")
+
+    def buffer(self, name, dtype=torch.float32):
+        """Zero-copy view of a named intermediate inside the bound workspace."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        check(self.lib.m3_engine_buffer(self.handle, name.encode(), C.byref(ptr), C.byref(nbytes)), "m3_engine_buffer")
+        ws = self._bound[3]
+        off = ptr.value - ws.data_ptr()
+        assert 0 <= off and off + nbytes.value <= ws.numel()
+        return ws[off: off + nbytes.value].view(dtype)

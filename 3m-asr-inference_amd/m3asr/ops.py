@@ -1,0 +1,299 @@
+"""Torch-tensor front end of the C ABI: device memory and streams come from PyTorch-ROCm, every
+computation is a libm3asr_hip.so call (include/m3asr.h).  No op here has a torch fallback."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "m3asr ops need contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    assert t is None or t.dtype == torch.float32, "fp32 tensor expected"
+    return _p(t)
+
+
+def _i32(t):
+    assert t is None or t.dtype == torch.int32, "int32 tensor expected"
+    return _p(t)
+
+
+# ---------------------------------------------------------------------------------------- MoE
+def moe_scatter_mapping(gate_idx, num_expert, want_pos=True):
+    lib = _lib.load()
+    g = gate_idx.reshape(-1)
+    S = g.numel()
+    mapping = torch.empty(S, dtype=torch.int32, device=g.device)
+    acc = torch.empty(num_expert + 1, dtype=torch.int32, device=g.device)
+    pos = torch.empty(S, dtype=torch.int32, device=g.device) if want_pos else None
+    check(lib.m3_moe_scatter_mapping(_i32(g), S, num_expert, _p(mapping), _p(acc), _p(pos), _stream()),
+          "m3_moe_scatter_mapping")
+    return mapping, acc, pos
+
+
+def moe_local_scatter(x, mapping, n_rows):
+    lib = _lib.load()
+    S, row_bytes = x.shape[0], x[0].numel() * x.element_size()
+    out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    check(lib.m3_moe_local_scatter(_p(x), _i32(mapping), S, row_bytes, _p(out), _stream()), "m3_moe_local_scatter")
+    return out
+
+
+def moe_local_gather(buf, mapping):
+    lib = _lib.load()
+    S = mapping.numel()
+    row_bytes = buf[0].numel() * buf.element_size()
+    out = torch.empty((S,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    check(lib.m3_moe_local_gather(_p(buf), _i32(mapping), S, row_bytes, _p(out), _stream()), "m3_moe_local_gather")
+    return out
+
+
+def moe_expert_workspace_size(S, E, D, F):
+    return _lib.load().m3_moe_expert_workspace_size(S, E, D, F)
+
+
+def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None):
+    """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue."""
+    lib = _lib.load()
+    S, D = x.shape
+    E, F = w1.shape[0], w1.shape[1]
+    need = moe_expert_workspace_size(S, E, D, F)
+    if workspace is None:
+        workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    check(lib.m3_moe_expert_ffn(_f32(x), _i32(gate_idx.reshape(-1)), _f32(w1), _f32(b1), _f32(w2), _f32(b2), S, E, D, F,
+                                _f32(gate_value.reshape(-1) if gate_value is not None else None), _f32(resid),
+                                float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
+                                workspace.numel(), _stream()), "m3_moe_expert_ffn")
+    return y
+
+
+def softmax_top1(logits, lens=None, rows_per_batch=0):
+    lib = _lib.load()
+    E = logits.shape[-1]
+    l2 = logits.reshape(-1, E)
+    S = l2.shape[0]
+    idx = torch.empty(S, dtype=torch.int32, device=logits.device)
+    val = torch.empty(S, dtype=torch.float32, device=logits.device)
+    check(lib.m3_softmax_top1(_f32(l2), E, _i32(lens), rows_per_batch, S, E, _p(idx), _p(val), _stream()),
+          "m3_softmax_top1")
+    return val, idx
+
+
+# ---------------------------------------------------------------------------------------- dense
+def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows_per_batch=0, mask_in=False,
+           mask_out=False, alpha=1.0, resid=None, out=None):
+    """y = resid + alpha * mask_out(act(LN(mask_in(cat[a,a2])) @ w^T + bias)); a (M,K1), w (N,K)."""
+    lib = _lib.load()
+    M, K1 = a.shape
+    N, K = w.shape
+    n_out = N // 2 if act == _lib.ACT_GLU else N
+    y = out if out is not None else torch.empty(M, n_out, dtype=torch.float32, device=a.device)
+    d = _lib.LinearDesc()
+    d.a, d.lda = a.data_ptr(), a.stride(0)
+    if a2 is not None:
+        d.a2, d.lda2, d.k1 = a2.data_ptr(), a2.stride(0), K1
+        assert K1 + a2.shape[1] == K
+    else:
+        assert K1 == K
+    d.w, d.bias = w.data_ptr(), (bias.data_ptr() if bias is not None else None)
+    d.y, d.ldy = y.data_ptr(), y.stride(0)
+    d.M, d.N, d.K = M, N, K
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    if lens is not None:
+        d.len, d.rows_per_batch = lens.data_ptr(), rows_per_batch
+    d.mask_in, d.mask_out = int(mask_in), int(mask_out)
+    d.act, d.alpha = act, float(alpha)
+    if resid is not None:
+        d.resid, d.ldr = resid.data_ptr(), resid.stride(0)
+    check(lib.m3_linear(C.byref(d), _stream()), "m3_linear")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps):
+    lib = _lib.load()
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.m3_layer_norm(_f32(x), _f32(gamma), _f32(beta), float(eps), _p(y), x.numel() // D, D, _stream()),
+          "m3_layer_norm")
+    return y
+
+
+def relpos_attention(qkv, p, pos_u, pos_v, lens, B, T, H, dk):
+    lib = _lib.load()
+    D = H * dk
+    out = torch.empty(B * T, D, dtype=torch.float32, device=qkv.device)
+    check(lib.m3_relpos_attention(_f32(qkv), qkv.stride(0), _f32(p), p.stride(0), _f32(pos_u), _f32(pos_v),
+                                  _i32(lens), B, T, H, dk, 1.0 / math.sqrt(dk), _p(out), D, _stream()),
+          "m3_relpos_attention")
+    return out
+
+
+def dwconv_ln_silu(z, w_kc, bias, gamma, beta, eps, B, T):
+    lib = _lib.load()
+    K, D = w_kc.shape
+    out = torch.empty_like(z)
+    check(lib.m3_dwconv_ln_silu(_f32(z), _f32(w_kc), _f32(bias), _f32(gamma), _f32(beta), float(eps), B, T, D, K,
+                                _p(out), _stream()), "m3_dwconv_ln_silu")
+    return out
+
+
+def subsample_conv1(feat, w9c, bias):
+    lib = _lib.load()
+    B, T, idim = feat.shape
+    Cc = w9c.shape[1]
+    T1, F1 = (T - 3) // 2 + 1, (idim - 3) // 2 + 1
+    out = torch.empty(B, T1, F1, Cc, dtype=torch.float32, device=feat.device)
+    check(lib.m3_subsample_conv1(_f32(feat), _f32(w9c), _f32(bias), B, T, idim, Cc, _p(out), _stream()),
+          "m3_subsample_conv1")
+    return out
+
+
+def subsample_conv2(x, w, bias):
+    lib = _lib.load()
+    B, T1, F1, Cc = x.shape
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    out = torch.empty(B, T2, F2, Cc, dtype=torch.float32, device=x.device)
+    check(lib.m3_subsample_conv2(_f32(x), _f32(w), _f32(bias), B, T1, F1, Cc, _p(out), _stream()),
+          "m3_subsample_conv2")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- small plugins
+def att_masked_softmax(scores, lens, scale):
+    lib = _lib.load()
+    B, H, T1, T2 = scores.shape
+    out = torch.empty_like(scores)
+    check(lib.m3_att_masked_softmax(_f32(scores), _i32(lens), B, H, T1, T2, float(scale), _p(out), _stream()),
+          "m3_att_masked_softmax")
+    return out
+
+
+def masked_fill(x, lens, fill):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    y = torch.empty_like(x)
+    check(lib.m3_masked_fill(_f32(x), _i32(lens), B, Cc, T, float(fill), _p(y), _stream()), "m3_masked_fill")
+    return y
+
+
+def glu(x, dim):
+    lib = _lib.load()
+    dim = dim % x.dim()
+    outer = int(math.prod(x.shape[:dim]))
+    inner = int(math.prod(x.shape[dim + 1:]))
+    Cc = x.shape[dim] // 2
+    shape = list(x.shape)
+    shape[dim] = Cc
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(lib.m3_glu(_f32(x), outer, Cc, inner, _p(y), _stream()), "m3_glu")
+    return y
+
+
+def mask_conv2d_sample(lens, left_padding, stride):
+    lib = _lib.load()
+    out = torch.empty_like(lens)
+    check(lib.m3_mask_conv2d_sample(_i32(lens), lens.numel(), left_padding, stride, _p(out), _stream()),
+          "m3_mask_conv2d_sample")
+    return out
+
+
+def scale(x, s):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.m3_scale(_f32(x), float(s), _p(y), x.numel(), _stream()), "m3_scale")
+    return y
+
+
+def unary(x, act):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.m3_unary(_f32(x), _p(y), x.numel(), act, _stream()), "m3_unary")
+    return y
+
+
+def binary(a, b, op):
+    """Broadcasting element-wise sum / prod (TensorRT ElementWise semantics: equal rank, dims 1 broadcast)."""
+    lib = _lib.load()
+    assert a.dim() == b.dim(), "elementwise operands must have equal rank"
+    shape = [max(x, y) for x, y in zip(a.shape, b.shape)]
+    nd = len(shape)
+
+    def strides(t):
+        return [0 if t.shape[i] == 1 and shape[i] != 1 else t.stride(i) for i in range(nd)]
+
+    y = torch.empty(shape, dtype=torch.float32, device=a.device)
+    arr = C.c_int64 * nd
+    check(lib.m3_binary(_f32(a), _f32(b), _p(y), arr(*shape), arr(*strides(a)), arr(*strides(b)), nd, op, _stream()),
+          "m3_binary")
+    return y
+
+
+def permute_copy(x, perm):
+    """Materialised permutation (TensorRT shuffle's transpose)."""
+    lib = _lib.load()
+    nd = x.dim()
+    out_shape = [x.shape[p] for p in perm]
+    in_strides = [x.stride(p) for p in perm]
+    y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+    arr = C.c_int64 * nd
+    check(lib.m3_permute(_f32(x), _p(y), arr(*out_shape), arr(*in_strides), nd, _stream()), "m3_permute")
+    return y
+
+
+def concat_last(a, b):
+    lib = _lib.load()
+    da, db = a.shape[-1], b.shape[-1]
+    rows = a.numel() // da
+    y = torch.empty(tuple(a.shape[:-1]) + (da + db,), dtype=torch.float32, device=a.device)
+    check(lib.m3_concat_last(_f32(a), da, _f32(b), db, _p(y), rows, _stream()), "m3_concat_last")
+    return y
+
+
+def softmax_lastdim(x):
+    lib = _lib.load()
+    n = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.m3_softmax(_f32(x), _p(y), x.numel() // n, n, _stream()), "m3_softmax")
+    return y
+
+
+def batched_matmul(a, b, transpose_b=False):
+    """a (..., M, K) @ b (..., K, N) (or b (..., N, K) transposed); leading dims equal or 1 in b/a."""
+    lib = _lib.load()
+    M, K = a.shape[-2:]
+    N = b.shape[-2] if transpose_b else b.shape[-1]
+    lead = [max(x, y) for x, y in zip(a.shape[:-2], b.shape[:-2])]
+    batch = int(math.prod(lead)) if lead else 1
+    na, nb = int(math.prod(a.shape[:-2])), int(math.prod(b.shape[:-2]))
+    assert na in (1, batch) and nb in (1, batch), "only full or fully-broadcast batch dims supported"
+    c = torch.empty(tuple(lead) + (M, N), dtype=torch.float32, device=a.device)
+    sa = 0 if na == 1 and batch > 1 else M * K
+    sb = 0 if nb == 1 and batch > 1 else b.shape[-2] * b.shape[-1]
+    check(lib.m3_batched_matmul(_f32(a), _f32(b), _p(c), batch, M, N, K, sa, sb, int(transpose_b), _stream()),
+          "m3_batched_matmul")
+    return c
+
+
+def depthwise_conv1d(x, w, bias, pad):
+    lib = _lib.load()
+    B, Cc, T = x.shape
+    K = w.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.m3_depthwise_conv1d(_f32(x), _f32(w.reshape(Cc, K)), _f32(bias), B, Cc, T, K, pad, _p(y), _stream()),
+          "m3_depthwise_conv1d")
+    return y

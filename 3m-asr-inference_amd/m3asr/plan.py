@@ -1,0 +1,156 @@
+"""The "plan": config + packed fp32 weights -- what replaces TensorRT's serialized engine
+(TRTAPI++/python/trt_helper/builder_helper.py:146-167 `build_engine`, infer.py:29-36 deserialize).
+
+``pack_weights`` turns a reference-layout state_dict (the keys of ``Net.state_dict()``, builder.py:131-134)
+into the layouts the HIP engine consumes (all build-time host work, done once):
+  * q/k/v projections fused into one [3D, D] weight + [3D] bias (one GEMM instead of three Linear layers,
+    attention.py:334-343);
+  * pointwise Conv1d weights (O, I, 1) viewed as [O, I]; depthwise (C,1,K) -> [K, C] (channel-last rows);
+  * subsampling conv1 (C,1,3,3) -> [9, C]; conv2 (O,I,3,3) -> [O,3,3,I] (implicit-GEMM K order);
+    the Linear after the convs gets its columns permuted from (c, f) to (f, c) because the engine keeps
+    activations channel-last (the reference flattens (B,C,T,F)->(B,T,C*F), subsampling.py:141-142);
+  * router_weights [D+De, E] -> transposed [E, D+De];
+  * eval BatchNorm in the conv module (cnn_module_norm='batch_norm') folded into the depthwise conv;
+  * the sinusoidal table ``pe`` (positional_encoding.py:40-48) for max_len positions;
+  * in expert-parallel mode only this rank's expert slice [rank*E_loc, (rank+1)*E_loc) is kept
+    (load_state_dict_comm, conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:259-273).
+
+File format (``save_plan`` / ``load_plan``): 8-byte magic, u64 header length, JSON header
+{config, tensors: {name: [offset, shape]}}, then raw little-endian fp32 data (256-B aligned).
+"""
+import json
+import math
+import struct
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .config import EncoderConfig
+
+MAGIC = b"M3ASRPL1"
+
+
+def positional_table(max_len, d):
+    pe = torch.zeros(max_len, d)
+    position = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def _pack_subsampling(sd, p, out):
+    w0 = sd[p + "conv.0.weight"]                         # (C,1,3,3)
+    C = w0.shape[0]
+    out[p + "conv.0.weight_9c"] = w0.reshape(C, 9).t().contiguous()
+    out[p + "conv.0.bias"] = sd[p + "conv.0.bias"]
+    out[p + "conv.2.weight_ohwi"] = sd[p + "conv.2.weight"].permute(0, 2, 3, 1).contiguous()
+    out[p + "conv.2.bias"] = sd[p + "conv.2.bias"]
+    wl = sd[p + "out.0.weight"]                          # (D, C*F2), column index c*F2 + f
+    F2 = wl.shape[1] // C
+    out[p + "out.0.weight"] = wl.view(-1, C, F2).permute(0, 2, 1).reshape(wl.shape[0], F2 * C).contiguous()
+    out[p + "out.0.bias"] = sd[p + "out.0.bias"]
+
+
+def _pack_block(sd, p, out, norm, moe, cfg):
+    for n in ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final"):
+        out[p + n + ".weight"] = sd[p + n + ".weight"]
+        out[p + n + ".bias"] = sd[p + n + ".bias"]
+    for n in ("feed_forward_macaron.w_1", "feed_forward_macaron.w_2", "self_attn.linear_out"):
+        out[p + n + ".weight"] = sd[p + n + ".weight"]
+        out[p + n + ".bias"] = sd[p + n + ".bias"]
+    a = p + "self_attn."
+    out[a + "qkv.weight"] = torch.cat([sd[a + "linear_q.weight"], sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0)
+    out[a + "qkv.bias"] = torch.cat([sd[a + "linear_q.bias"], sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0)
+    out[a + "linear_pos.weight"] = sd[a + "linear_pos.weight"]
+    out[a + "pos_bias_u"] = sd[a + "pos_bias_u"]
+    out[a + "pos_bias_v"] = sd[a + "pos_bias_v"]
+    c = p + "conv_module."
+    out[c + "pointwise_conv1.weight"] = sd[c + "pointwise_conv1.weight"].squeeze(-1)
+    out[c + "pointwise_conv1.bias"] = sd[c + "pointwise_conv1.bias"]
+    out[c + "pointwise_conv2.weight"] = sd[c + "pointwise_conv2.weight"].squeeze(-1)
+    out[c + "pointwise_conv2.bias"] = sd[c + "pointwise_conv2.bias"]
+    dw = sd[c + "depthwise_conv.weight"].squeeze(1)      # (C, K)
+    db = sd[c + "depthwise_conv.bias"]
+    if norm == "layer_norm":
+        out[c + "norm.weight"] = sd[c + "norm.weight"]
+        out[c + "norm.bias"] = sd[c + "norm.bias"]
+    else:  # eval BatchNorm1d folds into the depthwise conv: y = (x - mean) / sqrt(var + eps) * g + b
+        s = sd[c + "norm.weight"] / torch.sqrt(sd[c + "norm.running_var"] + 1e-5)
+        dw = dw * s.unsqueeze(1)
+        db = (db - sd[c + "norm.running_mean"]) * s + sd[c + "norm.bias"]
+    out[c + "depthwise_conv.weight_kc"] = dw.t().contiguous()
+    out[c + "depthwise_conv.bias"] = db
+    f = p + "feed_forward."
+    if not moe:
+        for n in ("w_1", "w_2"):
+            out[f + n + ".weight"] = sd[f + n + ".weight"]
+            out[f + n + ".bias"] = sd[f + n + ".bias"]
+    else:
+        out[f + "router_weights_t"] = sd[f + "router_weights"].t().contiguous()
+        if (f + "router_bias") in sd:
+            out[f + "router_bias"] = sd[f + "router_bias"]
+        lo = cfg.ep_rank * cfg.num_experts if cfg.ep_world_size > 1 else 0
+        for n in ("experts.w_1.weight", "experts.w_1.bias", "experts.w_2.weight", "experts.w_2.bias"):
+            t = sd[f + n]
+            if cfg.ep_world_size > 1 and t.shape[0] == cfg.num_experts * cfg.ep_world_size:
+                t = t[lo: lo + cfg.num_experts]
+            assert t.shape[0] == cfg.num_experts, "%s: %d experts, config says %d" % (f + n, t.shape[0], cfg.num_experts)
+            out[f + n] = t
+
+
+def pack_weights(state_dict, cfg: EncoderConfig):
+    """reference-layout state_dict (CPU fp32) -> OrderedDict of packed contiguous fp32 tensors."""
+    sd = {k: v.detach().float() for k, v in state_dict.items()}
+    out = OrderedDict()
+    _pack_subsampling(sd, "embed.subsampling.", out)
+    out["embed.after_norm.weight"] = sd["embed.after_norm.weight"]
+    out["embed.after_norm.bias"] = sd["embed.after_norm.bias"]
+    for i in range(cfg.embed_blocks):
+        _pack_block(sd, "embed.blocks.%d." % i, out, cfg.embed_cnn_module_norm, False, cfg)
+    _pack_subsampling(sd, "subsampling.", out)
+    out["after_norm.weight"] = sd["after_norm.weight"]
+    out["after_norm.bias"] = sd["after_norm.bias"]
+    for i in range(cfg.num_blocks):
+        _pack_block(sd, "blocks.%d." % i, out, cfg.cnn_module_norm, True, cfg)
+    out["out_linear.weight"] = sd["out_linear.weight"]
+    out["out_linear.bias"] = sd["out_linear.bias"]
+    out["pe"] = positional_table(cfg.max_len, cfg.attention_dim)
+    return OrderedDict((k, v.contiguous()) for k, v in out.items())
+
+
+def save_plan(path, cfg: EncoderConfig, packed, extra=None):
+    index, off = {}, 0
+    for k, v in packed.items():
+        index[k] = [off, list(v.shape)]
+        off += (v.numel() * 4 + 255) // 256 * 256
+    header = json.dumps({"config": json.loads(cfg.to_json()), "tensors": index, "extra": extra or {}}).encode()
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<Q", len(header)))
+        f.write(header)
+        pad = (-(16 + len(header))) % 256
+        f.write(b"\0" * pad)
+        for k, v in packed.items():
+            b = v.contiguous().numpy().astype("<f4", copy=False).tobytes()
+            f.write(b)
+            f.write(b"\0" * ((-len(b)) % 256))
+
+
+def load_plan(path):
+    """-> (EncoderConfig, OrderedDict name -> CPU fp32 tensor (memory-mapped), extra dict)"""
+    with open(path, "rb") as f:
+        if f.read(8) != MAGIC:
+            raise ValueError("%s is not an m3asr plan" % path)
+        (hl,) = struct.unpack("<Q", f.read(8))
+        header = json.loads(f.read(hl).decode())
+    base = 16 + hl
+    base += (-base) % 256
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    packed = OrderedDict()
+    for k, (off, shape) in header["tensors"].items():
+        n = int(np.prod(shape)) if shape else 1
+        arr = np.frombuffer(mm, dtype="<f4", count=n, offset=base + off).reshape(shape)
+        packed[k] = torch.from_numpy(np.array(arr, copy=True))
+    return EncoderConfig(**header["config"]), packed, header.get("extra", {})

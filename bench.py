@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encoder frames/sec of the 18L x 32e Conformer-MoE encoder on a 206-frame utterance
+(BASELINE.json `metric`; workload = configs[1]: 18-layer 32-expert fp32, batch 1 x 206 frames, all experts
+local).  One process per GPU; for N > 1 every rank runs its own utterance on its own replica of the
+engine (the path shards over independent utterances, SURVEY.md §8e: "B=1 multi-GPU = replicas"), no
+data-path collective, weak scaling.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = one encoder forward (feat, feat_len resident in HBM -> logits in HBM), replayed as a hipGraph.
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : the dominant kernel (grouped expert FFN) -- algorithmic bytes per launch / measured
+                 HIP-event duration on the engine's stream vs the 8 TB/s HBM peak;
+  cpu_baseline : the oracle's plain-torch fp32 forward of the same workload timed on the host cores
+                 (kind "port": the reference's CUDA/TensorRT path cannot be built here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "3m-asr-inference_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=206)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=18)
+    ap.add_argument("--experts", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fold-pos", action="store_true", help="precompute linear_pos(pos_emb) per shape")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
+    return ap.parse_args()
+
+
+def stage_times(eng, passes=20):
+    """HIP-event duration of every stage, recorded on the engine's own stream (averaged over passes)."""
+    names = eng.stage_names()
+    n = len(names)
+    acc = np.zeros(n)
+    st = eng.stream
+    for _ in range(passes):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record(st)
+        for i in range(n):
+            eng.run_stages(i, i + 1)
+            evs[i + 1].record(st)
+        st.synchronize()
+        acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
+    return names, acc / passes  # ms
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+
+    from m3asr.config import EncoderConfig, subsampled_len
+    from m3asr.weights import make_weights
+    from m3asr.engine import Engine
+
+    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts)
+    weights = make_weights(cfg, seed=0)
+    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos)
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        weights = None
+
+    # synthetic input: U[0,1) features as data/generate_trtexec_inputs.py:7 of the reference; each rank its own utterance
+    rng = np.random.default_rng(1234 + rank)
+    B, T = args.batch, args.frames
+    feat_cpu = torch.from_numpy(rng.random((B, T, cfg.input_dim), dtype=np.float32))
+    feat = feat_cpu.to(dev)
+    feat_len = torch.full((1, B), T, dtype=torch.int32, device=dev)
+    eng.bind(feat, feat_len)
+    use_graph = not args.no_graph
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward(use_graph=use_graph)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward(use_graph=use_graph)
+    eng.stream.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    frames_per_step = world * B * T
+    value = frames_per_step / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the engine's stream ----
+    roofline = None
+    if rank == 0:
+        names, ms = stage_times(eng)
+        if args.profile_stages:
+            for n_, m_ in sorted(zip(names, ms), key=lambda x: -x[1])[:40]:
+                print("%-40s %8.2f us" % (n_, m_ * 1e3), file=sys.stderr)
+            print("sum of stages %.3f ms, %d kernels" % (ms.sum(), eng.num_kernels()), file=sys.stderr)
+        idx = [i for i, n_ in enumerate(names) if n_.endswith("moe_local.expert")]
+        D, F, E, S = cfg.attention_dim, cfg.hidden_units, cfg.num_experts, B * subsampled_len(T)
+        # algorithmic bytes per launch: touched experts x (2DF + F + D) x 4 B  +  S x (D in + D out) x 4 B.
+        # acc_histogram of the last layer is live in the workspace; touched counts differ per layer by +-2, so
+        # use the per-layer routing recorded in gate_idx.
+        touched = []
+        for li in range(cfg.num_blocks):
+            g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
+            touched.append(len(np.unique(g[g >= 0])))
+        bytes_alg = np.array([t_ * (2 * D * F + F + D) * 4 + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
+        dur = ms[idx] * 1e-3
+        achieved = float((bytes_alg / dur).mean() / 1e9)
+        roofline = {"kernel": "expert_ffn_f32_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "avg_launch_us": round(float(dur.mean() * 1e6), 2),
+                    "alg_bytes_per_launch": int(bytes_alg.mean()), "experts_touched_mean": float(np.mean(touched))}
+
+    # ---- CPU baseline: the oracle (plain-torch fp32 restatement) on the host cores, rank 0, N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.encoder_ref import encoder_forward
+        fl_cpu = torch.full((B,), T, dtype=torch.int32)
+        cores = torch.get_num_threads()
+        times = []
+        encoder_forward(weights, cfg, feat_cpu, fl_cpu)
+        t_end = time.perf_counter() + args.cpu_seconds
+        while time.perf_counter() < t_end and len(times) < 50:
+            c0 = time.perf_counter()
+            ref_logits = encoder_forward(weights, cfg, feat_cpu, fl_cpu)
+            times.append(time.perf_counter() - c0)
+        med = float(np.median(times))
+        cpu = {"value": round(B * T / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d full forwards of the same 1x%d-frame %dL/%de workload (median %.1f ms), torch %s fp32" % (
+                   len(times), T, cfg.num_blocks, cfg.num_experts, med * 1e3, torch.__version__)}
+        # the checker: GPU logits of the timed workload vs the oracle's
+        got = eng._bound[2].cpu()
+        rel = float(((got - ref_logits).abs() / (ref_logits.abs() + 2e-1)).max())
+        cpu["gpu_vs_oracle_max_rel"] = round(rel, 6)
+
+    if rank == 0:
+        out = {"metric": "encoder frames/sec, 18Lx32e Conformer-MoE, 206-frame utterance",
+               "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "18-layer 32-expert fp32, batch=%dx%d frames per GPU, all experts local "
+                                      "(BASELINE.json configs[1])" % (B, T),
+                          "layers": cfg.num_blocks, "experts": cfg.num_experts, "frames": T, "batch_per_gpu": B,
+                          "parallelism": "replicas x%d" % world, "hip_graph": use_graph,
+                          "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

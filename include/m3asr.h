@@ -1,0 +1,239 @@
+/* m3asr.h -- C ABI of libm3asr_hip.so, the MI355X (gfx950) replacement for the reference's
+ * TRTAPI++/plugin library (libtrtplugin++.so) on the 3M-ASR Conformer-MoE encoder hot path.
+ *
+ * Conventions (mirroring the reference's plugin ABI, fmoe_expert_plugin.h:45-73):
+ *   - every tensor and every workspace is a CALLER-OWNED DEVICE pointer; weights are ordinary inputs,
+ *     never copied or owned by an op (README.md:225); plain pointers and sizes only, no framework types;
+ *   - `stream` is a hipStream_t passed as void*; ops only enqueue work on it (no host sync, no
+ *     allocation -> every entry point is hipGraph-capturable), unlike the reference's FMoE enqueue
+ *     which synchronises twice per layer (fmoe_expert_plugin.cpp:75-78,130);
+ *   - return value: 0 = ok, non-zero = failure (reference: `int enqueue(...)`), message via
+ *     m3_last_error() (reference only logs, common/common.h:26-38);
+ *   - dtype codes 0/1/2 = the reference's HelperConfig.plugin_data_type (builder_helper.py:47-57).
+ * Row layouts are row-major; "S" = B*T' tokens, D = idim, F = hidden_units, E = num_expert.
+ */
+#ifndef M3ASR_H_
+#define M3ASR_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3ASR_ABI_VERSION 1
+
+typedef void* m3_stream; /* hipStream_t */
+
+enum m3_dtype { M3_F32 = 0, M3_F16 = 1, M3_I8 = 2, M3_I32 = 3, M3_BF16 = 4 };
+
+/* activation / element-wise codes shared by several entry points */
+enum m3_act { M3_ACT_NONE = 0, M3_ACT_RELU = 1, M3_ACT_SILU = 2, M3_ACT_GLU = 3, M3_ACT_SIGMOID = 4 };
+enum m3_binop { M3_OP_SUM = 0, M3_OP_PROD = 1 };
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / registry.   Replaces: initLibNvInferPlugins + getPluginRegistry (plugin/exports.map:18-27),
+ * init_trt_plugin_plus (trt_plugin_plus.h:23) and PluginCreatorRegistry lookup (trt_plugin_plus.cpp:56-123).
+ * ---------------------------------------------------------------------------------------------- */
+int m3_abi_version(void);
+const char* m3_last_error(void);
+/* 1 if a creator for (name, version) is registered, else 0.  Names are the reference's plugin names. */
+int m3_registry_lookup(const char* plugin_name, const char* plugin_version);
+int m3_registry_count(void);
+const char* m3_registry_name(int index);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic plugin objects.   Replaces IPluginCreator::createPlugin / IPluginV2DynamicExt
+ * {getOutputDimensions, getWorkspaceSize, enqueue, serialize, clone, destroy} for the eight plugins of
+ * the hot path (fmoe_expert_plugin.h:45-73 is the template all of them follow).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct m3_tensor { /* = nvinfer1::PluginTensorDesc + data pointer */
+  void* data;
+  int32_t dtype; /* enum m3_dtype */
+  int32_t ndim;
+  int64_t shape[8];
+} m3_tensor;
+
+enum m3_field_type { M3_FIELD_FLOAT32 = 1, M3_FIELD_INT32 = 5 }; /* values of nvinfer1::PluginFieldType */
+typedef struct m3_field {                                          /* = nvinfer1::PluginField */
+  const char* name;
+  const void* data;
+  int32_t type;
+  int32_t length;
+} m3_field;
+
+typedef struct m3_plugin m3_plugin;
+
+/* NULL on unknown plugin or bad/missing attributes (reference creators return nullptr,
+ * fmoe_expert_plugin.cpp:356-359). */
+m3_plugin* m3_plugin_create(const char* plugin_name, const char* plugin_version, const m3_field* fields,
+                            int n_fields);
+m3_plugin* m3_plugin_clone(const m3_plugin* plugin);
+void m3_plugin_destroy(m3_plugin* plugin);
+const char* m3_plugin_type(const m3_plugin* plugin);
+int m3_plugin_num_outputs(const m3_plugin* plugin);
+/* fills outputs[i].{dtype,ndim,shape} from the input descriptors (data pointers ignored) */
+int m3_plugin_output_dims(const m3_plugin* plugin, const m3_tensor* inputs, int n_in, m3_tensor* outputs,
+                          int n_out);
+size_t m3_plugin_workspace_size(const m3_plugin* plugin, const m3_tensor* inputs, int n_in,
+                                const m3_tensor* outputs, int n_out);
+int m3_plugin_enqueue(m3_plugin* plugin, const m3_tensor* inputs, int n_in, m3_tensor* outputs, int n_out,
+                      void* workspace, size_t workspace_bytes, m3_stream stream);
+/* POD serialisation of the attributes (reference: serialize.hpp:36-52) */
+size_t m3_plugin_serialization_size(const m3_plugin* plugin);
+int m3_plugin_serialize(const m3_plugin* plugin, void* buffer, size_t bytes);
+m3_plugin* m3_plugin_deserialize(const char* plugin_name, const char* plugin_version, const void* buffer,
+                                 size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * MoE hot path, direct entry points (what FMoEExpertPluginDynamic's enqueue is made of).
+ * ---------------------------------------------------------------------------------------------- */
+/* Replaces ComputeScatterMapping (fmoe_expert_kernel.h:26-27; fmoe_expert_kernel.cu:25-90).
+ * gate_idx[S] int32 in [0,E) (or <0 = dropped row) -> mapping[S], acc_histogram[E+1], pos[S] (inverse
+ * permutation, may be NULL).  Stable within an expert. */
+int m3_moe_scatter_mapping(const int32_t* gate_idx, int S, int num_expert, int32_t* mapping,
+                           int32_t* acc_histogram, int32_t* pos, m3_stream stream);
+/* Replaces ComputeScatterMappingCopy (fmoe_expert_kernel.cu:92-128) = FastMoE local_scatter
+ * (fmoe/functions.py:72):  out[mapping[s]] = x[s];  rows of row_bytes (multiple of 16). */
+int m3_moe_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out,
+                         m3_stream stream);
+/* Replaces ComputeGatherrMappingCopy (fmoe_expert_kernel.cu:191-227) = FastMoE local_gather
+ * (fmoe/functions.py:194):  out[s] = buf[mapping[s]] (0 for dropped rows). */
+int m3_moe_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out,
+                        m3_stream stream);
+/* Workspace of m3_moe_expert_ffn / FMoEExpertPluginDynamic (reference layout: fmoe_expert_plugin.cpp:224-239). */
+size_t m3_moe_expert_workspace_size(int S, int num_expert, int idim, int hidden_units);
+/* Replaces compute_fmoe_expert (fmoe_expert_plugin.cpp:36-142): y[s] = SiLU(x[s] W1[g]^T + b1[g]) W2[g]^T + b2[g]
+ * for g = gate_idx[s] >= 0, else 0.  x,y [S][D] f32; w1 [E][F][D], b1 [E][F], w2 [E][D][F], b2 [E][D]
+ * (FMoELinear layout, fmoe/layers.py:34-38).  Optional fused epilogue (all may be NULL / 1.0):
+ *   y[s] = resid[s] + alpha * gate_value[s] * y[s], then LayerNorm(ln_gamma, ln_beta, ln_eps). */
+int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, const float* b1,
+                      const float* w2, const float* b2, int S, int num_expert, int idim, int hidden_units,
+                      const float* gate_value, const float* resid, float alpha, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, float* y, void* workspace, size_t workspace_bytes,
+                      m3_stream stream);
+/* Replaces ComputeSoftmaxAndTop1 (softmax_topk_kernel.cu:88-120): logits [S][ld] -> idx[S], value[S];
+ * frames t >= len[b] (t = s % rows_per_batch, b = s / rows_per_batch) get idx -1 / value 0; len may be NULL. */
+int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
+                    int32_t* idx, float* value, m3_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense building blocks (TensorRT-native layers of the reference + the small plugins).
+ * ---------------------------------------------------------------------------------------------- */
+/* Linear / point-wise conv with fused prologue+epilogue.  Replaces addLinear_ (torch_network_helper.py:573-605),
+ * addConv1d k=1 (:199-225), LayerNorm plugin (layer_norm_plugin.cpp:78-113), masked_fill, GLU, SiLU/ReLU,
+ * addScale + addAdd.   y[M][ldy] = resid + alpha * mask_out( act( LN(mask_in(a))[M][K] . w[N][K]^T + bias ) ).
+ * a2 != NULL: A = cat([a (K1 cols), a2 (K-K1 cols)], -1) (router input, positionwise_feed_forward.py:225).
+ * act = M3_ACT_GLU halves the output width (columns n and n+N/2 are paired, torch GLU dim=-1). */
+typedef struct m3_linear_desc {
+  const float* a; int32_t lda;
+  const float* a2; int32_t lda2; int32_t k1;
+  const float* w; const float* bias;
+  float* y; int32_t ldy;
+  int32_t M, N, K;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const int32_t* len; int32_t rows_per_batch; int32_t mask_in; int32_t mask_out;
+  int32_t act; float alpha;
+  const float* resid; int32_t ldr;
+} m3_linear_desc;
+int m3_linear(const m3_linear_desc* desc, m3_stream stream);
+
+/* LayerNormPluginDynamic (layer_norm_plugin.cpp:78-113) -- with eps, as PyTorch. */
+int m3_layer_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int dim,
+                  m3_stream stream);
+/* Fused rel-pos attention core; replaces attention.py:347-384 + :199-236 (shuffles, 3 batched matmuls,
+ * AttMaskedSoftmaxPluginDynamic).  qkv [B*T][ldq] = (q|k|v), p [T][ldp], pos_u/pos_v [H][dk], out [B*T][ldo]. */
+int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, const float* pos_u,
+                        const float* pos_v, const int32_t* len, int B, int T, int H, int dk, float scale,
+                        float* out, int ldo, m3_stream stream);
+/* Depthwise conv (k odd, pad (k-1)/2) + LayerNorm (gamma NULL = none) + SiLU on channel-last rows;
+ * replaces convolution.py:134-152.  w_kc [K][D] = depthwise weight (D,1,K) transposed. */
+int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
+                      const float* beta, float eps, int B, int T, int D, int K, float* out, m3_stream stream);
+/* Conv2dSubsampling4 (subsampling.py:103-145) on channel-last data: conv1 (1->C, 3x3, s2) + ReLU. */
+int m3_subsample_conv1(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
+                       float* out, m3_stream stream);
+/* second conv (C->C, 3x3, s2) + ReLU as implicit GEMM: in (B,T1,F1,C) -> out (B,T2,F2,C); w [C][3][3][C]. */
+int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C,
+                       float* out, m3_stream stream);
+
+/* small plugins */
+int m3_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
+                          float* out, m3_stream stream);                 /* att_masked_softmax_plugin.cpp:84-108 */
+int m3_masked_fill(const float* x, const int32_t* len, int B, int C, int T, float fill, float* y,
+                   m3_stream stream);                                     /* masked_fill_plugin.cpp:87-108 */
+int m3_glu(const float* x, int outer, int C, int inner, float* y, m3_stream stream); /* glu_plugin.cpp:90-134 */
+int m3_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, int stride, int32_t* len_out,
+                          m3_stream stream);                              /* mask_conv2d_sample_plugin.cpp:70-80 */
+int m3_scale(const float* x, float scale, float* y, size_t n, m3_stream stream); /* rel_positional_encoding_kernel.cu:62-69 */
+
+/* TensorRT-native element-wise / shuffle / concat / matmul layers used through network_helper */
+int m3_unary(const float* x, float* y, size_t n, int act, m3_stream stream);
+int m3_binary(const float* a, const float* b, float* y, const int64_t* shape, const int64_t* strides_a,
+              const int64_t* strides_b, int ndim, int op, m3_stream stream);
+int m3_permute(const float* x, float* y, const int64_t* out_shape, const int64_t* in_strides, int ndim,
+               m3_stream stream);
+int m3_concat_last(const float* a, int da, const float* b, int db, float* y, size_t rows, m3_stream stream);
+int m3_softmax(const float* x, float* y, size_t rows, int n, m3_stream stream);
+int m3_batched_matmul(const float* a, const float* b, float* c, int batch, int M, int N, int K,
+                      int64_t stride_a, int64_t stride_b, int transpose_b, m3_stream stream);
+int m3_depthwise_conv1d(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad,
+                        float* y, m3_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-encoder engine.  Replaces the TensorRT engine built by builder.py:36-98 and run by
+ * infer.py:38-103 (IExecutionContext::execute_v2): feat (B,T,idim) f32 + feat_len (1,B) i32 -> logits (B,T',V).
+ * The weight blob is the "plan" payload produced by the builder (packed fp32, offsets in `table`).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct m3_engine m3_engine;
+
+typedef struct m3_engine_config {
+  int32_t input_dim, output_dim;
+  int32_t attention_dim, attention_heads, num_blocks;
+  int32_t embed_dim, embed_heads, embed_linear_units, embed_blocks;
+  int32_t num_experts, hidden_units;
+  int32_t cnn_module_kernel;
+  int32_t cnn_layer_norm;        /* 1 = LayerNorm in the conv module, 0 = (folded) batch norm */
+  int32_t embed_cnn_layer_norm;
+  int32_t router_with_bias, keep_expert_output;
+  int32_t ep_world_size, ep_rank; /* expert parallel: this rank owns experts [rank*E_loc, (rank+1)*E_loc) */
+  int32_t fold_pos_proj;         /* 1 = linear_pos(pos_emb) computed once per T' at shape set-up */
+  int32_t debug_taps;            /* 1 = keep every block's output (the reference's DumpTensor taps) */
+} m3_engine_config;
+
+typedef struct m3_weight_entry {
+  const char* name; /* packed tensor name, see m3asr/plan.py */
+  const void* data; /* device pointer */
+  int64_t numel;
+} m3_weight_entry;
+
+m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entry* table, int n_entries);
+void m3_engine_destroy(m3_engine* engine);
+/* T' for T input frames (MaskConv2dSample twice, mask_conv2d_sample_kernel.cu:34-35) */
+int m3_engine_output_frames(int T);
+size_t m3_engine_workspace_size(const m3_engine* engine, int B, int T);
+/* Enqueue one encoder forward.  All pointers device, caller-owned.  use_graph=1 replays a hipGraph
+ * captured for this (B, T, pointers) on first use. */
+int m3_engine_forward(m3_engine* engine, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                      void* workspace, size_t workspace_bytes, int use_graph, m3_stream stream);
+/* Staged execution (used by the expert-parallel host driver, m3asr/ep.py, and by per-stage timing):
+ * m3_engine_prepare binds shape + caller-owned buffers and builds the ordered kernel-stage list;
+ * stages [first, last) are then enqueued with m3_engine_run.  Stage names are
+ * "<prefix>.<op>", e.g. "embed.blocks.0.ffn_macaron.w1", "blocks.3.moe_router", "blocks.3.moe_local.expert",
+ * "logits"; one kernel per stage.  In expert-parallel mode the host replaces the "blocks.N.moe_local.*" stages by
+ * local index -> RCCL all-to-all -> m3_moe_expert_ffn on the received rows -> all-to-all back -> combine. */
+int m3_engine_prepare(m3_engine* engine, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                      void* workspace, size_t workspace_bytes);
+int m3_engine_num_stages(const m3_engine* engine);
+const char* m3_engine_stage_name(const m3_engine* engine, int index);
+int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream stream);
+/* Device address (inside the bound workspace) and size of a named intermediate of the prepared shape:
+ * "x" (residual stream, S*D), "xn" (LayerNorm'd MoE input), "embed", "lens" (B int32),
+ * "blocks.N.gate_idx" / "gate_value" / "mapping" / "acc_histogram", "blocks.N.out" (debug_taps only). */
+int m3_engine_buffer(const m3_engine* engine, const char* name, void** ptr, size_t* bytes);
+int m3_engine_num_kernels(const m3_engine* engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3ASR_H_ */

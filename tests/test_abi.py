@@ -1,0 +1,123 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU, and
+exports exactly the symbols include/m3asr.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "m3asr.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(m3_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from m3asr import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "3m-asr-inference_amd"), "-j8"])
+    return _lib.LIB_PATH
+
+
+def test_header_symbols_are_exported(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    names = _declared()
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in m3asr.h but not exported: %s" % missing
+
+
+def test_ctypes_table_matches_header(lib_path):
+    from m3asr import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.m3_abi_version() == 1
+
+
+def test_registry_names_are_the_references(lib_path):
+    """Plugin names/versions of the reference (e.g. fmoe_expert_plugin.h:28-29)."""
+    from m3asr import _lib
+    lib = _lib.load()
+    for name in ["FMoEExpertPluginDynamic", "SoftmaxTopKPluginDynamic", "AttMaskedSoftmaxPluginDynamic",
+                 "LayerNormPluginDynamic", "MaskedFillPluginDynamic", "GluPluginDynamic",
+                 "MaskConv2dSamplePluginDynamic", "RelPositionalEncodingPluginDynamic"]:
+        assert lib.m3_registry_lookup(name.encode(), b"1") == 1
+        assert lib.m3_registry_lookup(name.encode(), b"2") == 0
+    assert lib.m3_registry_lookup(b"NoSuchPlugin", b"1") == 0
+    listed = {lib.m3_registry_name(i).decode() for i in range(lib.m3_registry_count())}
+    assert "FMoEExpertPluginDynamic" in listed
+
+
+def test_plugin_creation_attribute_checks(lib_path):
+    """Creators return NULL on missing attributes (fmoe_expert_plugin.cpp:356-359) and keep a message."""
+    import numpy as np
+    from m3asr import _lib
+    lib = _lib.load()
+
+    def fields(d):
+        arr = (_lib.Field * len(d))()
+        keep = []
+        for i, (k, v) in enumerate(d.items()):
+            a = np.asarray(v)
+            keep.append(a)
+            arr[i].name = k.encode()
+            arr[i].data = a.ctypes.data
+            arr[i].type = _lib.FIELD_INT32 if a.dtype == np.int32 else _lib.FIELD_FLOAT32
+            arr[i].length = a.size
+        return arr, len(d), keep
+
+    good = {"data_type": np.array([0], np.int32), "num_expert": np.array([32], np.int32),
+            "idim": np.array([512], np.int32), "hidden_units": np.array([1024], np.int32)}
+    arr, n, keep = fields(good)
+    p = lib.m3_plugin_create(b"FMoEExpertPluginDynamic", b"1", arr, n)
+    assert p and lib.m3_plugin_type(p) == b"FMoEExpertPluginDynamic" and lib.m3_plugin_num_outputs(p) == 1
+    # workspace query is pure host arithmetic
+    t = _lib.Tensor()
+    t.ndim, t.dtype = 3, 0
+    t.shape[0], t.shape[1], t.shape[2] = 1, 50, 512
+    ws = lib.m3_plugin_workspace_size(p, ctypes.byref(t), 1, None, 0)
+    assert ws == lib.m3_moe_expert_workspace_size(50, 32, 512, 1024) and ws >= 16 * 50 * 512 * 4
+    # serialize / deserialize / clone round trip
+    nbytes = lib.m3_plugin_serialization_size(p)
+    buf = ctypes.create_string_buffer(nbytes)
+    assert lib.m3_plugin_serialize(p, buf, nbytes) == 0
+    q = lib.m3_plugin_deserialize(b"FMoEExpertPluginDynamic", b"1", buf, nbytes)
+    c = lib.m3_plugin_clone(p)
+    assert q and c and lib.m3_plugin_workspace_size(q, ctypes.byref(t), 1, None, 0) == ws
+    assert not lib.m3_plugin_deserialize(b"GluPluginDynamic", b"1", buf, nbytes)
+    for h in (p, q, c):
+        lib.m3_plugin_destroy(h)
+    bad = dict(good)
+    del bad["idim"]
+    arr, n, keep = fields(bad)
+    assert not lib.m3_plugin_create(b"FMoEExpertPluginDynamic", b"1", arr, n)
+    assert b"attribute" in lib.m3_last_error()
+    half = dict(good, data_type=np.array([1], np.int32))
+    arr, n, keep = fields(half)
+    assert not lib.m3_plugin_create(b"FMoEExpertPluginDynamic", b"1", arr, n)      # fp16: not implemented (as in the reference)
+    # output dims: SoftmaxTopK -> value (B,T,1) f32 + idx (B,T,1) i32
+    arr, n, keep = fields({"data_type": np.array([0], np.int32)})
+    sp = lib.m3_plugin_create(b"SoftmaxTopKPluginDynamic", b"1", arr, n)
+    ins = (_lib.Tensor * 2)()
+    ins[0].ndim, ins[0].dtype = 3, 0
+    ins[0].shape[0], ins[0].shape[1], ins[0].shape[2] = 2, 50, 32
+    ins[1].ndim, ins[1].dtype = 2, 3
+    ins[1].shape[0], ins[1].shape[1] = 1, 2
+    outs = (_lib.Tensor * 2)()
+    assert lib.m3_plugin_output_dims(sp, ins, 2, outs, 2) == 0
+    assert list(outs[0].shape[:3]) == [2, 50, 1] and outs[1].dtype == 3
+    lib.m3_plugin_destroy(sp)
+
+
+def test_host_side_size_queries(lib_path):
+    from m3asr import _lib
+    lib = _lib.load()
+    assert [lib.m3_engine_output_frames(t) for t in (206, 50, 500, 7, 6)] == [50, 11, 124, 1, 0]
+    assert lib.m3_moe_expert_workspace_size(0, 32, 512, 1024) == 0
+    assert lib.m3_moe_expert_workspace_size(50, 32, 512, 1000) == 0     # hidden not a multiple of 64

@@ -1,0 +1,95 @@
+"""GPU parity of the whole encoder engine (m3_engine_* through the C ABI) against
+ (a) the committed golden vectors (reference's own forward, tests/golden/), and
+ (b) the CPU oracle on fresh seeded inputs incl. ragged batches.
+Tolerance: north_star asks logits within 1e-3 relative fp32; we hold rtol 1e-3 on |logit| plus a small
+absolute floor for near-zero logits (atol 2e-4, ~1e-4 of the typical logit magnitude 2.4)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from m3asr.config import EncoderConfig
+from m3asr.engine import Engine
+from m3asr.weights import make_weights
+from oracle.encoder_ref import encoder_forward, sub_len
+
+RTOL, ATOL = 1e-3, 2e-4
+
+
+def _run(cfg, w, feat, feat_len, **kw):
+    eng = Engine.from_state_dict(cfg, w, **kw)
+    f, l = feat.cuda().contiguous(), feat_len.to(torch.int32).view(1, -1).cuda().contiguous()
+    out = eng(f, l).cpu()
+    return eng, out
+
+
+def _check(out, want, out_len):
+    valid = torch.arange(out.shape[1]).view(1, -1) < torch.as_tensor(out_len).view(-1, 1)
+    err = (out - want).abs()[valid]
+    bound = (ATOL + RTOL * want.abs())[valid]
+    assert bool((err <= bound).all()), "max abs err %.3e, max |ref| %.3e" % (float(err.max()), float(want[valid].abs().max()))
+    return float(err.max())
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid", "cfg2"])
+def test_engine_matches_golden(golden, name):
+    cfg, z = golden(name)
+    w = make_weights(cfg, seed=int(z["weight_seed"]))
+    eng, out = _run(cfg, w, torch.from_numpy(z["feat"]), torch.from_numpy(z["feat_len"]), debug_taps=True)
+    assert tuple(out.shape) == z["logits"].shape
+    _check(out, torch.from_numpy(z["logits"]), z["out_len"])
+    valid = np.arange(out.shape[1])[None, :] < z["out_len"][:, None]
+    # routing decisions of the first layers: integer outputs, exact
+    for i in range(z["gate_idx"].shape[0]):
+        gi = eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().numpy().reshape(valid.shape)
+        assert np.array_equal(gi[valid], z["gate_idx"][i][..., 0][valid])
+        assert (gi[~valid] == -1).all()
+    hist = np.stack([np.diff(eng.buffer("blocks.%d.acc_histogram" % i, torch.int32).cpu().numpy())
+                     for i in range(cfg.num_blocks)])
+    if bool(valid.all()):
+        assert np.array_equal(hist, z["expert_hist"])
+    if "block_out" in z.files:
+        for i in range(cfg.num_blocks):
+            bo = eng.buffer("blocks.%d.out" % i).cpu().view(out.shape[0], out.shape[1], -1)
+            _check(bo, torch.from_numpy(z["block_out"][i]), z["out_len"])
+
+
+def test_engine_ragged_batch_vs_oracle():
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=2)
+    w = make_weights(cfg, seed=5)
+    lengths = [206, 57, 333, 120]
+    g = torch.Generator().manual_seed(9)
+    feat = torch.rand(len(lengths), max(lengths), cfg.input_dim, generator=g)
+    fl = torch.tensor(lengths, dtype=torch.int32)
+    want = encoder_forward(w, cfg, feat, fl)
+    eng, out = _run(cfg, w, feat, fl)
+    _check(out, want, sub_len(fl.long()))
+
+
+def test_engine_graph_replay_and_fold_are_bit_identical():
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=2)
+    feat = torch.rand(1, 206, cfg.input_dim, generator=torch.Generator().manual_seed(1)).cuda()
+    fl = torch.tensor([[206]], dtype=torch.int32).cuda()
+    eng = Engine.from_state_dict(cfg, w)
+    eager = eng(feat, fl).clone()
+    for _ in range(3):
+        eng.forward(use_graph=True)
+    eng.stream.synchronize()
+    assert torch.equal(eng._bound[2], eager)
+    eng2 = Engine.from_state_dict(cfg, w, fold_pos_proj=True)
+    assert torch.equal(eng2(feat, fl), eager)
+    assert eng2.num_kernels() < eng.num_kernels()
+
+
+def test_engine_rejects_bad_input():
+    from m3asr._lib import M3Error
+    cfg = EncoderConfig.tiny()
+    eng = Engine.from_state_dict(cfg, make_weights(cfg, seed=0))
+    with pytest.raises(M3Error):
+        eng(torch.rand(1, 5, cfg.input_dim).cuda(), torch.tensor([[5]], dtype=torch.int32).cuda())   # T < 7
+    w = make_weights(cfg, seed=0)
+    del w["blocks.0.norm_ff.weight"]
+    with pytest.raises(KeyError):
+        Engine.from_state_dict(cfg, w)
