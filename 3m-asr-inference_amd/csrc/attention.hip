@@ -10,23 +10,28 @@
 // Inputs: qkv [B*T][ldq] = (q | k | v) rows from the fused QKV projection, p [T][ldp] = linear_pos(pos_emb)
 // (shared by the batch), pos_bias_u/v [h][dk].  Output ctx [B*T][ldo] with heads merged, i.e. the
 // "attn_transpose_and_reshape" shuffle is folded into the store.
-// One wave per (batch, head, 16-query tile); keys are walked in tiles of 16 with an online softmax;
-// the probability tile goes C-layout -> A-layout through a 1 KB LDS patch.
+// One workgroup (4 waves) per (batch, head, 16-query tile): wave w walks key tiles w, w+4, ... with an
+// online softmax (so a 50-frame utterance is one key tile per wave = one memory round trip), the
+// probability tile goes C-layout -> A-layout through a 1 KB LDS patch per wave, and the four partial
+// (max, sum, O) states are merged through LDS.
 #include "common.h"
 #include "kernels.h"
 
 namespace m3 {
 
 template <int DK>
-__global__ __launch_bounds__(64) void relpos_attention_kernel(const float* __restrict__ qkv, int ldq,
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, int ldq,
                                                               const float* __restrict__ pmat, int ldp,
                                                               const float* __restrict__ pos_u,
                                                               const float* __restrict__ pos_v,
                                                               const int32_t* __restrict__ row_len, int T, int D,
                                                               float scale, float* __restrict__ out, int ldo) {
   constexpr int KS = DK / 16;
-  __shared__ __attribute__((aligned(16))) float ps[16][20];
-  const int lane = threadIdx.x, col = lane & 15, kq = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
+  __shared__ float mo[4][16][DK + 1];   // per-wave partial O
+  __shared__ float mm[4][16], ml[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+  float (*ps)[20] = ps_all[wave];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
   const int len = min(row_len ? row_len[b] : T, T);
   const size_t brow = (size_t)b * T;
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(64) void relpos_attention_kernel(const float* __res
     l_run[r] = 0.f;
   }
 
-  for (int j0 = 0; j0 < len; j0 += 16) {
+  for (int j0 = 16 * wave; j0 < len; j0 += 64) {
     const int kj = min(j0 + col, T - 1);
     const float* krow = qkv + (brow + kj) * ldq + D + h * DK + 4 * kq;
     const float* prow = pmat + (size_t)kj * ldp + h * DK + 4 * kq;
@@ -90,23 +95,43 @@ __global__ __launch_bounds__(64) void relpos_attention_kernel(const float* __res
       for (int n = 0; n < KS; ++n) o[n][r] *= corr;
       ps[4 * kq + r][col] = pexp;
     }
-    __syncthreads();
+    // ps is private to this wave and a wave's LDS operations execute in order: only the compiler has
+    // to be kept from moving the transposed read across the writes (no s_barrier needed)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[col][4 * kq]);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int n = 0; n < KS; ++n)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) o[n] = mfma16(pa[jj], vb[n][jj], o[n]);
   }
 
+  // ---- merge the four waves' partial softmax states ----
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = q0 + 4 * kq + r;
-    if (i < T) {
-      const float inv = 1.f / l_run[r];
-#pragma unroll
-      for (int n = 0; n < KS; ++n) out[(brow + i) * ldo + h * DK + 16 * n + col] = o[n][r] * inv;
+    if (col == 0) {
+      mm[wave][4 * kq + r] = m_run[r];
+      ml[wave][4 * kq + r] = l_run[r];
     }
+#pragma unroll
+    for (int n = 0; n < KS; ++n) mo[wave][4 * kq + r][16 * n + col] = o[n][r];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * DK; idx += 256) {
+    const int i = idx / DK, d = idx - i * DK;
+    const int qrow = q0 + i;
+    if (qrow >= T) continue;
+    const float m_tot = fmaxf(fmaxf(mm[0][i], mm[1][i]), fmaxf(mm[2][i], mm[3][i]));
+    float l_tot = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = expf(mm[w][i] - m_tot);   // waves without a key tile hold m = -inf -> factor 0
+      l_tot += ml[w][i] * f;
+      acc += mo[w][i][d] * f;
+    }
+    out[(brow + qrow) * ldo + h * DK + d] = acc / l_tot;
   }
 }
 
@@ -118,7 +143,7 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
   dim3 grid(cdiv(T, 16), H, B);
   const int D = H * dk;
 #define M3_ATT_CASE(DK_)                                                                                   \
-  hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(64), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
+  hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
                      pos_v, row_len, T, D, scale, out, ldo)
   switch (dk) {
     case 16: M3_ATT_CASE(16); break;

@@ -31,19 +31,34 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __rest
     const int c = (lane + 64 * i) * 4;
     v[i] = (c < D) ? ldg4(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int k = 0; k < K; ++k) {
-    const int tt = t + k - pad;
-    if (tt < 0 || tt >= T) continue;  // zero padding at the tensor edge (wave-uniform branch)
-    const float* zr = z + ((size_t)b * T + tt) * D;
+  // taps in chunks of 5: all loads of a chunk are issued before its FMAs (edge taps read a clamped row
+  // and are multiplied by 0 = the conv's zero padding), so a frame costs ~3 memory round trips, not K
+  for (int k0 = 0; k0 < K; k0 += 5) {
+    f32x4 zz[5][NV], ww[5][NV];
+    float on[5];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < D) {
-        const f32x4 zz = ldg4(zr + c), ww = ldg4(w_kc + (size_t)k * D + c);
+    for (int kk = 0; kk < 5; ++kk) {
+      const int k = min(k0 + kk, K - 1);
+      const int tt = t + k - pad;
+      on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
+      const float* zr = z + ((size_t)b * T + min(max(tt, 0), T - 1)) * D;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] = fmaf(zz[j], ww[j], v[i][j]);
+      for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+          zz[kk][i] = ldg4(zr + c);
+          ww[kk][i] = ldg4(w_kc + (size_t)k * D + c);
+        }
       }
     }
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk)
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if ((lane + 64 * i) * 4 < D) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = fmaf(zz[kk][i][j] * on[kk], ww[kk][i][j], v[i][j]);
+        }
   }
   float mean = 0.f, rstd = 1.f;
   if (gamma != nullptr) {

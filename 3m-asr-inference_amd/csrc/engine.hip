@@ -66,6 +66,7 @@ struct m3_engine {
   Lin out_linear;
   const float* pe = nullptr;
   int64_t pe_rows = 0;
+  const float* pos_all = nullptr;   // [(embed_blocks + num_blocks) * D][D]: every block's linear_pos weight
 
   // bound shape
   int B = 0, T = 0, Tp = 0, S = 0;
@@ -120,7 +121,6 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
   if (!load_lin(e, p + "feed_forward_macaron.w_1.", F, D, true, &b->mac1) ||
       !load_lin(e, p + "feed_forward_macaron.w_2.", D, F, true, &b->mac2) ||
       !load_lin(e, p + "self_attn.qkv.", 3 * D, D, true, &b->qkv) ||
-      !load_lin(e, p + "self_attn.linear_pos.", D, D, false, &b->pos) ||
       !load_lin(e, p + "self_attn.linear_out.", D, D, true, &b->out) ||
       !load_lin(e, p + "conv_module.pointwise_conv1.", 2 * D, D, true, &b->pw1) ||
       !load_lin(e, p + "conv_module.pointwise_conv2.", D, D, true, &b->pw2))
@@ -197,7 +197,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.emb = cv.take<float>((size_t)S * D);
   p.h1 = cv.take<float>((size_t)S * F);
   p.qkv = cv.take<float>((size_t)S * 3 * D);
-  p.pbuf = cv.take<float>((size_t)Tp * D);
+  p.pbuf = cv.take<float>((size_t)Tp * D * (c.num_blocks + c.embed_blocks));
   p.ctx = cv.take<float>((size_t)S * D);
   p.glu = cv.take<float>((size_t)S * D);
   p.dw = cv.take<float>((size_t)S * D);
@@ -208,7 +208,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.moe_ws_bytes = carve_moe_workspace(nullptr, S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
   p.moe_ws = cv.take<char>(p.moe_ws_bytes * (size_t)(c.debug_taps ? c.num_blocks : 1));
   p.taps = c.debug_taps ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * S * D) : nullptr;
-  p.pfold = c.fold_pos_proj ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * Tp * D) : nullptr;
+  p.pfold = nullptr;
   p.bytes = cv.off;
   return p;
 }
@@ -269,20 +269,16 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     g.A = x; g.lda = D; g.W = w.qkv.w; g.bias = w.qkv.b; g.Y = pl.qkv; g.ldy = 3 * D; g.M = S; g.N = 3 * D; g.K = D;
     g.ln_gamma = w.n_mha.g; g.ln_beta = w.n_mha.b; g.ln_eps = eps;
     add_gemm(e, pfx + "att.qkv", g);
-    const float* pmat = pl.pbuf;
-    if (c.fold_pos_proj) {
-      pmat = pl.pfold + (size_t)tap_index * Tp * D;  // filled once at prepare()
-    } else {
-      GemmParams pp;
-      pp.A = e->pe; pp.lda = D; pp.W = w.pos.w; pp.Y = pl.pbuf; pp.ldy = D; pp.M = Tp; pp.N = D; pp.K = D;
-      add_gemm(e, pfx + "att.pos", pp);
-    }
+    // p = linear_pos(pos_emb) of all blocks comes from ONE GEMM per forward ("pos_all" stage):
+    // block i's slice is columns [i*D, (i+1)*D) of pbuf [T'][n_blocks*D]
+    const int ldp = (c.num_blocks + c.embed_blocks) * D;
+    const float* pmat = pl.pbuf + (size_t)tap_index * D;
     const float* qkv = pl.qkv; float* ctx = pl.ctx;
     const float* pu = w.pos_u; const float* pv = w.pos_v;
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
-      return launch_relpos_attention(qkv, 3 * D, pmat, D, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s);
+      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s);
     });
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
@@ -325,9 +321,11 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     float* gval = pl.gate_val + (size_t)layer * S;
     const float* ng = w.n_ff.g; const float* nb = w.n_ff.b;
     GemmParams r;
-    r.mode = GEMM_A_CONCAT2; r.A = pl.emb; r.lda = De; r.K1 = De; r.A2 = xn; r.lda2 = D;
+    r.mode = GEMM_A_CONCAT2; r.A = pl.emb; r.lda = De; r.K1 = De; r.A2 = x; r.lda2 = D;
     r.W = w.router.w; r.bias = w.router.b; r.Y = rl; r.ldy = Etot; r.M = S; r.N = Etot; r.K = De + D;
-    add_stage(e, pfx + "moe_ln", 1, [=](hipStream_t s) { return launch_layernorm(x, ng, nb, eps, xn, S, D, s); });
+    // LayerNorm(norm_ff) rides in the router GEMM: applied to the x half of cat([embed, x]) and written
+    // out once as xn, the expert FFN's input
+    r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
     add_gemm(e, pfx + "moe_router", r);
     add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
       return launch_softmax_top1(rl, Etot, lens, Tp, S, Etot, gidx, gval, s);
@@ -404,6 +402,7 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
     e->pe = (const float*)it->second.data;
     e->pe_rows = it->second.numel / D;
   }
+  if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all)) return fail(nullptr);
   e->eblocks.resize(c.embed_blocks);
   for (int i = 0; i < c.embed_blocks; ++i)
     if (!load_block(e, "embed.blocks." + std::to_string(i) + ".", De, c.embed_linear_units, K, c.embed_cnn_layer_norm,
@@ -447,11 +446,20 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
   {
     int32_t* lens = pl.lens;
-    add_stage(e, "lens", 2, [=](hipStream_t s) {
-      int rc = launch_mask_conv2d_sample(feat_len, B, 2, 2, lens, s);
-      if (rc) return rc;
-      return launch_mask_conv2d_sample(lens, B, 2, 2, lens, s);
-    });
+    add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); });
+  }
+  // ---- p = linear_pos(pe[:T']) for all blocks at once (attention.py:345; input-independent, so with
+  //      fold_pos_proj it is computed once per bound shape instead of once per forward) ----
+  {
+    const int nb = c.num_blocks + c.embed_blocks;
+    GemmParams pp;
+    pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
+    if (c.fold_pos_proj) {
+      if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
+      M3_CHECK_HIP(hipStreamSynchronize(nullptr));
+    } else {
+      add_gemm(e, "pos_all", pp);
+    }
   }
   // ---- embed encoder (conformer_embed_domain_acc.py:149-181) ----
   build_subsample(e, "embed.subsample.", e->sub_e, De, pl, pl.x);
@@ -481,17 +489,6 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
   e->buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 
-  // input-independent p = linear_pos(pe[:T']) per block, computed once per bound shape
-  if (c.fold_pos_proj) {
-    hipStream_t s = nullptr;
-    for (int i = 0; i < c.embed_blocks + c.num_blocks; ++i) {
-      const BlockW& w = i < c.embed_blocks ? e->eblocks[i] : e->mblocks[i - c.embed_blocks];
-      GemmParams pp;
-      pp.A = e->pe; pp.lda = D; pp.W = w.pos.w; pp.Y = pl.pfold + (size_t)i * Tp * D; pp.ldy = D; pp.M = Tp; pp.N = D; pp.K = D;
-      if (int rc = launch_gemm_f32(pp, s)) return rc;
-    }
-    M3_CHECK_HIP(hipStreamSynchronize(s));
-  }
   return (int)e->stages.size();
 }
 

@@ -12,11 +12,13 @@
 //   (tensor_network_helper.py:406-471).
 //
 // Shape regime: M = B*T' tokens (50 .. ~2000), N, K in 512..4608: every weight element is used by
-// only M rows, so the kernel is a weight-streaming kernel.  Layout: one workgroup = 16 output
-// columns (x2 for GLU) x 16*MT rows; its 4 waves split K round-robin in 16-deep steps, each
-// wave streams its W rows straight into VGPRs (float4 per lane = 16 rows x 64 B per instruction,
-// two 4-step groups in flight) and reads A the same way from L2; partial tiles are summed
-// through LDS (no atomics -> bitwise reproducible).
+// only M rows, so this is a weight-streaming, latency-sensitive kernel.  One workgroup = 16 output
+// columns (x2 for GLU) x 16*MT rows; its 4 waves split K round-robin in 16-deep steps; each wave
+// streams its W rows and A rows straight into VGPRs (float4 per lane = 16 rows x 64 B per
+// instruction), two groups of G steps in flight; partial tiles are summed through LDS in a fixed
+// order (no atomics -> bitwise reproducible).  Small M is split into 16-row tiles (MT = 1) so a
+// 50-token utterance still spreads over 128-384 workgroups; the tiles of one weight column block
+// are placed on the same XCD (blockIdx % 8) so the weight tile is fetched from HBM once.
 #include "common.h"
 #include "kernels.h"
 
@@ -25,36 +27,76 @@ namespace m3 {
 template <int MT, bool GLU>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   constexpr int NT = GLU ? 2 : 1;
+  constexpr int G = MT == 1 ? 8 : (MT == 2 ? 6 : 4);  // K-steps per in-flight group
+  constexpr int RW = 4 * MT;                          // rows per wave in the LayerNorm prologue
   __shared__ float red[4][MT * NT][256];
   __shared__ float stats[16 * MT][2];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const int m0 = blockIdx.y * (16 * MT);
   const int Nout = GLU ? (p.N >> 1) : p.N;
 
-  // ---- optional LayerNorm statistics of this workgroup's A rows (two-pass, fp32) ----
+  // ---- workgroup -> (column tile, row tile); XCD-aware when the column-tile count allows ----
+  int n_tile, m_tile;
+  {
+    const int id = blockIdx.x;
+    if (p.xcd_swizzle) {
+      const int j = id >> 3;
+      m_tile = j % p.m_tiles;
+      n_tile = (j / p.m_tiles) * 8 + (id & 7);
+    } else {
+      n_tile = id % p.n_tiles;
+      m_tile = id / p.n_tiles;
+    }
+  }
+  const int n0 = n_tile * 16;
+  const int m0 = m_tile * (16 * MT);
+
+  // ---- optional LayerNorm statistics of this workgroup's A rows: all rows of a wave in flight ----
   if (p.ln_gamma != nullptr) {
-    for (int r = wave; r < 16 * MT; r += 4) {
-      const int m = min(m0 + r, p.M - 1);
-      const float* row = p.A + (size_t)m * p.lda;
-      float s = 0.f;
-      for (int k = lane * 4; k < p.K; k += 256) {
-        f32x4 v = ldg4(row + k);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+    const float* lnA = p.ln_on_a2 ? p.A2 : p.A;
+    const int ldl = p.ln_on_a2 ? p.lda2 : p.lda;
+    const int Kl = p.ln_on_a2 ? (p.K - p.K1) : p.K;
+    const int nv = (Kl + 255) >> 8;                    // float4 per lane per row (<= 4 -> K <= 1024)
+    for (int c = 0; c < MT; ++c) {                     // 4 rows of this wave at a time, all loads in flight
+      f32x4 v[4][4];
+      float s[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(m0 + wave * RW + 4 * c + r, p.M - 1);
+        const float* row = lnA + (size_t)m * ldl;
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = (lane + 64 * i) * 4;
+          v[r][i] = (i < nv && k < Kl) ? ldg4(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
-      const float mean = wave_sum(s) / (float)p.K;
-      float q = 0.f;
-      for (int k = lane * 4; k < p.K; k += 256) {
-        f32x4 v = ldg4(row + k);
-        float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+        s[r] = wave_sum(s[r]) / (float)Kl;
       }
-      const float var = wave_sum(q) / (float)p.K;
-      if (lane == 0) {
-        stats[r][0] = mean;
-        stats[r][1] = rsqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = (lane + 64 * i) * 4;
+          if (i < nv && k < Kl) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float d = v[r][i][j] - s[r];
+              q += d * d;
+            }
+          }
+        }
+        q = wave_sum(q) / (float)Kl;
+        if (lane == 0) {
+          stats[wave * RW + 4 * c + r][0] = s[r];
+          stats[wave * RW + 4 * c + r][1] = rsqrtf(q + p.ln_eps);
+        }
       }
     }
     __syncthreads();
@@ -100,6 +142,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = p.K >> 4;
+  const int ln_k0 = p.ln_on_a2 ? p.K1 : 0;             // first K index the LayerNorm applies to
+  float* ln_out_row[MT];                               // side output of the normalised rows (router fusion)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + 16 * mt + col;
+    ln_out_row[mt] = (p.ln_out != nullptr && n_tile == 0 && m < p.M) ? p.ln_out + (size_t)m * p.ld_ln_out + 4 * kq
+                                                                      : nullptr;
+  }
 
   auto a_offset = [&](int k) -> int {  // wave-uniform k (multiple of 16) -> element offset in the A row
     if (p.mode == GEMM_A_CONV3X3S2) {
@@ -110,12 +160,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     return k;
   };
 
-  // two groups of 4 K-steps in flight (registers only; nothing is shared between waves)
-  f32x4 wbuf[2][4][NT], abuf[2][4][MT];
+  // two groups of G K-steps in flight (registers only; nothing is shared between waves)
+  f32x4 wbuf[2][G][NT], abuf[2][G][MT];
   auto load_group = [&](int g, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = wave + 4 * (4 * g + i);
+    for (int i = 0; i < G; ++i) {
+      const int s = wave + 4 * (G * g + i);
       if (s < nsteps) {
         const int k = s << 4;
 #pragma unroll
@@ -133,20 +183,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   };
   auto compute_group = [&](int g, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = wave + 4 * (4 * g + i);
+    for (int i = 0; i < G; ++i) {
+      const int s = wave + 4 * (G * g + i);
       if (s < nsteps) {
+        const int k = s << 4;
+        const bool do_ln = p.ln_gamma != nullptr && k >= ln_k0;
         f32x4 g4, b4;
-        if (p.ln_gamma != nullptr) {
-          g4 = ldg4(p.ln_gamma + (s << 4) + 4 * kq);
-          b4 = ldg4(p.ln_beta + (s << 4) + 4 * kq);
+        if (do_ln) {
+          g4 = ldg4(p.ln_gamma + (k - ln_k0) + 4 * kq);
+          b4 = ldg4(p.ln_beta + (k - ln_k0) + 4 * kq);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           f32x4 a = abuf[buf][i][mt];
-          if (p.ln_gamma != nullptr) {
+          if (do_ln) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = (a[j] - a_mean[mt]) * a_rstd[mt] * g4[j] + b4[j];
+            if (ln_out_row[mt] != nullptr) stg4(ln_out_row[mt] + (k - ln_k0), a);
           }
           if (a_zero[mt]) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -158,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
   };
 
-  const int ngroups = (nsteps + 15) >> 4;
+  const int ngroups = (nsteps + 4 * G - 1) / (4 * G);
   load_group(0, 0);
   for (int g = 0; g < ngroups; g += 2) {
     if (g + 1 < ngroups) load_group(g + 1, 1);
@@ -209,7 +262,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   }
 }
 
-int launch_gemm_f32(const GemmParams& p, hipStream_t stream) {
+int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
+  GemmParams p = pin;
   M3_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   M3_REQUIRE((p.K & 15) == 0, "gemm: K=%d must be a multiple of 16", p.K);
   M3_REQUIRE((p.lda & 3) == 0, "gemm: lda=%d must be a multiple of 4", p.lda);
@@ -219,12 +273,21 @@ int launch_gemm_f32(const GemmParams& p, hipStream_t stream) {
     M3_REQUIRE((p.K1 & 15) == 0 && p.A2 != nullptr && (p.lda2 & 3) == 0, "gemm: bad concat operands");
   if (p.mode == GEMM_A_CONV3X3S2)
     M3_REQUIRE((p.conv_C & 15) == 0 && p.K == 9 * p.conv_C, "gemm: conv mode needs K=9*C, C%%16==0");
-  if (p.ln_gamma) M3_REQUIRE(p.mode == GEMM_A_PLAIN, "gemm: LN prologue needs plain A");
+  if (p.ln_gamma) {
+    M3_REQUIRE(p.mode == GEMM_A_PLAIN || (p.mode == GEMM_A_CONCAT2 && p.ln_on_a2),
+               "gemm: LN prologue needs plain A (or the A2 half of a concat)");
+    M3_REQUIRE((p.ln_on_a2 ? p.K - p.K1 : p.K) <= 1024, "gemm: LN prologue supports rows up to 1024 wide");
+  }
+  M3_REQUIRE(!p.ln_on_a2 || p.mode == GEMM_A_CONCAT2, "gemm: ln_on_a2 needs concat mode");
+  M3_REQUIRE(p.ln_out == nullptr || p.ln_gamma != nullptr, "gemm: ln_out needs the LN prologue");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm: mask needs row_len");
   const int Nout = glu ? p.N / 2 : p.N;
-  // row tile: 16*MT rows per workgroup
-  const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
-  dim3 grid(cdiv(Nout, 16), cdiv(p.M, 16 * mt));
+  // row tile: 16*MT rows per workgroup; short inputs are cut into 16-row tiles to fill the chip
+  const int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
+  p.n_tiles = cdiv(Nout, 16);
+  p.m_tiles = cdiv(p.M, 16 * mt);
+  p.xcd_swizzle = (p.n_tiles % 8 == 0) ? 1 : 0;
+  dim3 grid(p.n_tiles * p.m_tiles);
 #define M3_GEMM_CASE(MT_, GLU_)                                                          \
   hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_>), grid, dim3(256), 0, stream, p)
   if (glu) {

@@ -19,6 +19,8 @@ struct GemmParams {
   int mode = GEMM_A_PLAIN;
   // prologue
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 0.f;
+  int ln_on_a2 = 0;                                       // CONCAT2: LayerNorm only the A2 half (router input)
+  float* ln_out = nullptr; int ld_ln_out = 0;             // optional side output of the normalised rows
   const int32_t* row_len = nullptr; int rows_per_batch = 0;  // frame t = row % rows_per_batch is padded if t >= row_len[row / rows_per_batch]
   int mask_in = 0, mask_out = 0;
   // implicit 3x3 stride-2 conv over a channel-last (B,T1,F1,C) input -> rows (b,t2,f2)
@@ -27,6 +29,8 @@ struct GemmParams {
   int act = ACT_NONE;
   float alpha = 1.f;
   const float* resid = nullptr; int ldr = 0;
+  // filled by launch_gemm_f32
+  int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
 int launch_gemm_f32(const GemmParams& p, hipStream_t stream);
 
@@ -62,6 +66,7 @@ int launch_glu(const float* x, int outer, int C, int inner, float* y, hipStream_
 int launch_scale(const float* x, float scale, float* y, size_t n, hipStream_t stream);
 int launch_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, int stride, int32_t* len_out,
                               hipStream_t stream);
+int launch_subsample_lens(const int32_t* len_in, int B, int32_t* len_out, hipStream_t stream);
 int launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t stream);
 int launch_binary_bcast(const float* a, const float* b, float* y, const int64_t* shape, const int64_t* sa,
                         const int64_t* sb, int nd, int op, hipStream_t stream);

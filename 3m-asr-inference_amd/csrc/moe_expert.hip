@@ -48,22 +48,40 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
   const float bias1 = b1[(size_t)e * F + f0 + 16 * wave + col];
   const int nsub = D >> 4;                   // 16-column output tiles of phase 2
 
+  // One stream of weight loads per wave: g1 groups of 8 W1 k-steps, then g2 groups of 2 W2 tiles
+  // (8 float4 each), double-buffered so 8-16 float4 per lane stay in flight across the phase change.
+  const int g1 = (ksteps1 + 7) >> 3;
+  const int g2 = (((nsub + 3) >> 2) + 1) >> 1;   // same for every wave (the barrier sits inside the loop)
+  const int total = g1 + g2;
+
   for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
     const int nrows = min(16 * MT, row_hi - r0);
+    float* slab_base = slab + ((size_t)slice * S + r0) * D;
 
-    // W1 prefetch (first group) is issued before the X staging so HBM latency overlaps it
     f32x4 wb[2][8];
-    auto load_w1 = [&](int g, int buf) {
+    auto load_group = [&](int g, int buf) {      // buf is a literal at every call site
+      if (g < g1) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int s = 8 * g + i;
-        if (s < ksteps1) wb[buf][i] = ldg4(w1row + (s << 4));
+        for (int i = 0; i < 8; ++i) {
+          const int s = 8 * g + i;
+          if (s < ksteps1) wb[buf][i] = ldg4(w1row + (s << 4));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sub = wave + 4 * (2 * (g - g1) + j);
+          if (sub < nsub) {
+            const float* p = w2 + ((size_t)e * D + 16 * sub + col) * F + f0 + 4 * kq;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) wb[buf][4 * j + st] = ldg4(p + 16 * st);
+          }
+        }
       }
     };
-    load_w1(0, 0);
+    load_group(0, 0);   // issued before the X staging so HBM latency overlaps it
 
     // ---- gather token rows into LDS (fused local_scatter) ----
-    __syncthreads();  // previous row tile finished reading xs / hs
+    __syncthreads();    // previous row tile is done with xs / hs
     for (int i = wave; i < 16 * MT; i += 4) {
       float* dst = xs + i * xs_ld;
       if (i < nrows) {
@@ -75,90 +93,70 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
     }
     __syncthreads();
 
-    // ---- phase 1: H[:, f0+16w .. +16) over the full K = D ----
     f32x4 acc1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ngroups = (ksteps1 + 7) >> 3;
-    for (int g = 0; g < ngroups; g += 2) {
-      if (g + 1 < ngroups) load_w1(g + 1, 1);
+    f32x4 hfrag[MT][4];
+
+    // phase change: H = SiLU(acc1 + b1) -> LDS -> A fragments of phase 2
+    auto transition = [&]() {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int s = 8 * g + i;
-        if (s < ksteps1) {
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + (16 * mt + col) * xs_ld + (s << 4) + 4 * kq);
+        for (int r = 0; r < 4; ++r)
+          hs[(16 * mt + 4 * kq + r) * hs_ld + 16 * wave + col] = silu(acc1[mt][r] + bias1);
+      __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[mt] = mfma16(a[j], wb[0][i][j], acc1[mt]);
-          }
-        }
-      }
-      if (g + 1 < ngroups) {
-        if (g + 2 < ngroups) load_w1(g + 2, 0);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          hfrag[mt][st] = *reinterpret_cast<const f32x4*>(hs + (16 * mt + col) * hs_ld + 16 * st + 4 * kq);
+    };
+    auto compute = [&](int g, int buf) {
+      if (g < g1) {   // phase 1: H[:, f0+16w .. +16) += X[:, 16s..] . W1^T
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int s = 8 * (g + 1) + i;
+          const int s = 8 * g + i;
           if (s < ksteps1) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const f32x4 a = *reinterpret_cast<const f32x4*>(xs + (16 * mt + col) * xs_ld + (s << 4) + 4 * kq);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc1[mt] = mfma16(a[j], wb[1][i][j], acc1[mt]);
+              for (int j = 0; j < 4; ++j) acc1[mt] = mfma16(a[j], wb[buf][i][j], acc1[mt]);
+            }
+          }
+        }
+      } else {        // phase 2: Ypart[:, 16*sub .. +16) = H[:, slice] . W2[e][:, slice]^T
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sub = wave + 4 * (2 * (g - g1) + j);
+          if (sub < nsub) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc2 = mfma16(hfrag[mt][st][jj], wb[buf][4 * j + st][jj], acc2);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 16 * mt + 4 * kq + r;
+                if (i < nrows) slab_base[(size_t)i * D + 16 * sub + col] = acc2[r];
+              }
             }
           }
         }
       }
-    }
-
-    // first W2 tile of this wave is requested before the barrier
-    f32x4 w2b[2][4];
-    auto load_w2 = [&](int sub, int buf) {
-      if (sub < nsub) {
-        const float* p = w2 + ((size_t)e * D + 16 * sub + col) * F + f0 + 4 * kq;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) w2b[buf][st] = ldg4(p + 16 * st);
-      }
     };
-    load_w2(wave, 0);
 
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        hs[(16 * mt + 4 * kq + r) * hs_ld + 16 * wave + col] = silu(acc1[mt][r] + bias1);
-    __syncthreads();
-
-    // ---- phase 2: Ypart[:, 16*sub .. +16) for sub = wave, wave+4, ..  (K = 64 hidden units) ----
-    f32x4 hfrag[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int st = 0; st < 4; ++st)
-        hfrag[mt][st] = *reinterpret_cast<const f32x4*>(hs + (16 * mt + col) * hs_ld + 16 * st + 4 * kq);
-
-    float* slab_base = slab + ((size_t)slice * S + r0) * D;
-    auto tile2 = [&](int sub, int buf) {  // buf is a literal at every call site (static register index)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc2 = mfma16(hfrag[mt][st][j], w2b[buf][st][j], acc2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * mt + 4 * kq + r;
-          if (i < nrows) slab_base[(size_t)i * D + 16 * sub + col] = acc2[r];
-        }
-      }
-    };
-    for (int sub = wave; sub < nsub; sub += 8) {
-      load_w2(sub + 4, 1);
-      tile2(sub, 0);
-      if (sub + 4 < nsub) {
-        load_w2(sub + 8, 0);
-        tile2(sub + 4, 1);
+    for (int g = 0; g < total; g += 2) {
+      if (g + 1 < total) load_group(g + 1, 1);
+      if (g == g1) transition();
+      compute(g, 0);
+      if (g + 1 < total) {
+        if (g + 2 < total) load_group(g + 2, 0);
+        if (g + 1 == g1) transition();
+        compute(g + 1, 1);
       }
     }
   }
@@ -231,9 +229,13 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
       f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
       if (m >= 0) {
         y = ldg4(b2 + (size_t)g * D + c);
-        for (int k = 0; k < n_slices; ++k) {
-          const f32x4 t = ldg4(slab + ((size_t)k * S + m) * D + c);
-          y += t;
+        for (int k0 = 0; k0 < n_slices; k0 += 8) {   // 8 slab rows in flight, summed in slice order
+          f32x4 t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            t[j] = (k0 + j < n_slices) ? ldg4(slab + ((size_t)(k0 + j) * S + m) * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y += t[j];
         }
       }
       y *= (alpha * gate);

@@ -361,6 +361,21 @@ int launch_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, in
   return 0;
 }
 
+// both MaskConv2dSample applications of Conv2dSubsampling4 in one launch (subsampling.py:119-137)
+__global__ void subsample_lens_kernel(const int32_t* __restrict__ in, int B, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    const int l1 = (in[i] - 3) / 2 + 1;
+    out[i] = (l1 - 3) / 2 + 1;
+  }
+}
+int launch_subsample_lens(const int32_t* len_in, int B, int32_t* len_out, hipStream_t stream) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(subsample_lens_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, len_in, B, len_out);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- small strided-batched matmul (compat path only)
 // c[b] (M,N) = a[b] (M,K) . b[b] (K,N)  or  a[b] . b[b]^T with b (N,K); sa/sb = batch strides (0 = broadcast).
 __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ a, const float* __restrict__ b,

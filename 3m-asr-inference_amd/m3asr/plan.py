@@ -63,7 +63,6 @@ def _pack_block(sd, p, out, norm, moe, cfg):
     a = p + "self_attn."
     out[a + "qkv.weight"] = torch.cat([sd[a + "linear_q.weight"], sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0)
     out[a + "qkv.bias"] = torch.cat([sd[a + "linear_q.bias"], sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0)
-    out[a + "linear_pos.weight"] = sd[a + "linear_pos.weight"]
     out[a + "pos_bias_u"] = sd[a + "pos_bias_u"]
     out[a + "pos_bias_v"] = sd[a + "pos_bias_v"]
     c = p + "conv_module."
@@ -117,6 +116,10 @@ def pack_weights(state_dict, cfg: EncoderConfig):
     out["out_linear.weight"] = sd["out_linear.weight"]
     out["out_linear.bias"] = sd["out_linear.bias"]
     out["pe"] = positional_table(cfg.max_len, cfg.attention_dim)
+    # every block's linear_pos weight stacked: p for all blocks = one GEMM per forward (attention.py:345)
+    out["pos_all.weight"] = torch.cat(
+        [sd["embed.blocks.%d.self_attn.linear_pos.weight" % i] for i in range(cfg.embed_blocks)] +
+        [sd["blocks.%d.self_attn.linear_pos.weight" % i] for i in range(cfg.num_blocks)], 0)
     return OrderedDict((k, v.contiguous()) for k, v in out.items())
 
 

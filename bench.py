@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--fold-pos", action="store_true", help="precompute linear_pos(pos_emb) per shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--routing", choices=["balanced", "random"], default="balanced",
+                    help="balanced: calibrate the synthetic router weights so tokens spread over the experts "
+                         "(a trained 3M-ASR router is load-balanced by its aux losses); random: raw N(0,0.5) init")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
     return ap.parse_args()
 
@@ -62,6 +65,31 @@ def stage_times(eng, passes=20):
         st.synchronize()
         acc += np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
     return names, acc / passes  # ms
+
+
+def balance_router(eng, cpu_weights=None):
+    """Synthetic-weight calibration (no effect on the code path being timed): random router weights send
+    almost every frame of an utterance to the same 3-4 experts because the frames share a large common
+    component.  A trained 3M-ASR router is load-balanced (sparse-L1 + importance losses,
+    positionwise_feed_forward.py:155-160), so per layer we project the mean router input out of
+    router_weights, layer by layer on the device, using the staged engine API.  The resulting expert
+    histogram is reported with the result."""
+    names = eng.stage_names()
+    first = 0
+    for li in range(eng.cfg.num_blocks):
+        idx = names.index("blocks.%d.moe_router" % li)
+        eng.run_stages(first, idx + 1)
+        eng.stream.synchronize()
+        mu = torch.cat([eng.buffer("embed").view(-1, eng.cfg.embed_dim).mean(0),
+                        eng.buffer("xn").view(-1, eng.cfg.attention_dim).mean(0)])
+        w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
+        w -= torch.outer(w @ mu, mu) / (mu @ mu)
+        eng.run_stages(idx, idx + 1)                                              # logits with the new weights
+        first = idx + 1
+        if cpu_weights is not None:
+            cpu_weights["blocks.%d.feed_forward.router_weights" % li] = w.t().contiguous().cpu()
+    eng.run_stages(first, len(names))
+    eng.stream.synchronize()
 
 
 def main():
@@ -93,6 +121,8 @@ def main():
     feat = feat_cpu.to(dev)
     feat_len = torch.full((1, B), T, dtype=torch.int32, device=dev)
     eng.bind(feat, feat_len)
+    if args.routing == "balanced":
+        balance_router(eng, weights)
     use_graph = not args.no_graph
 
     def barrier():
@@ -123,8 +153,9 @@ def main():
     if rank == 0:
         names, ms = stage_times(eng)
         if args.profile_stages:
-            for n_, m_ in sorted(zip(names, ms), key=lambda x: -x[1])[:40]:
-                print("%-40s %8.2f us" % (n_, m_ * 1e3), file=sys.stderr)
+            for n_, m_ in zip(names, ms):
+                if not (n_.startswith("blocks.") or n_.startswith("embed.blocks.")) or ".0." in n_ or ".9." in n_:
+                    print("%-40s %8.2f us" % (n_, m_ * 1e3), file=sys.stderr)
             print("sum of stages %.3f ms, %d kernels" % (ms.sum(), eng.num_kernels()), file=sys.stderr)
         idx = [i for i, n_ in enumerate(names) if n_.endswith("moe_local.expert")]
         D, F, E, S = cfg.attention_dim, cfg.hidden_units, cfg.num_experts, B * subsampled_len(T)
@@ -141,7 +172,8 @@ def main():
         roofline = {"kernel": "expert_ffn_f32_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
                     "avg_launch_us": round(float(dur.mean() * 1e6), 2),
-                    "alg_bytes_per_launch": int(bytes_alg.mean()), "experts_touched_mean": float(np.mean(touched))}
+                    "alg_bytes_per_launch": int(bytes_alg.mean()),
+                    "experts_touched_mean": round(float(np.mean(touched)), 2)}
 
     # ---- CPU baseline: the oracle (plain-torch fp32 restatement) on the host cores, rank 0, N=1 only ----
     cpu = None
@@ -174,7 +206,8 @@ def main():
                                       "(BASELINE.json configs[1])" % (B, T),
                           "layers": cfg.num_blocks, "experts": cfg.num_experts, "frames": T, "batch_per_gpu": B,
                           "parallelism": "replicas x%d" % world, "hip_graph": use_graph,
-                          "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos)},
+                          "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
+                          "routing": args.routing},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
