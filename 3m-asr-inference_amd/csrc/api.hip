@@ -50,7 +50,7 @@ int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, con
              w.bytes);
   int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
   if (rc) return rc;
-  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, w.slab, stream);
+  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
   if (rc) return rc;
   return launch_moe_combine(w.slab, F / kExpertSlice, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma,
                             ln_beta, ln_eps, y, S, D, stream);
@@ -101,6 +101,7 @@ int m3_linear(const m3_linear_desc* d, m3_stream stream) {
   p.W = d->w; p.bias = d->bias; p.Y = d->y; p.ldy = d->ldy;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
+  p.ln_wsum = d->ln_wsum; p.ln_wbeta = d->ln_wbeta;
   p.row_len = d->len; p.rows_per_batch = d->rows_per_batch; p.mask_in = d->mask_in; p.mask_out = d->mask_out;
   p.act = d->act; p.alpha = d->alpha; p.resid = d->resid; p.ldr = d->ldr;
   return launch_gemm_f32(p, (hipStream_t)stream);

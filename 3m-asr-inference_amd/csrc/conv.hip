@@ -13,102 +13,91 @@
 
 namespace m3 {
 
-// z, out: [B*T][D]; w_kc: [K][D] (repacked from (D,1,K)); one wave per frame.
-template <int NV>
-__global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
-                                                             const float* __restrict__ bias,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps, int T,
-                                                             int D, int K, float* __restrict__ out, int rows) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= rows) return;
+// z, out: [B*T][D]; w_kc: [K][D] (repacked from (D,1,K)).  One workgroup per frame, one float4 of
+// channels per thread (D/4 threads): all K taps (z rows t-pad..t+pad and their weights) are loaded
+// before the first FMA, so a frame costs one memory round trip; edge taps read a clamped row and are
+// multiplied by 0 (= the conv's zero padding).  LayerNorm statistics go through a small LDS tree.
+template <int KT>
+__global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int T,
+                                                              int D, int K, float* __restrict__ out) {
+  __shared__ float red[2][16];
+  const int row = blockIdx.x;
   const int b = row / T, t = row % T;
   const int pad = (K - 1) / 2;
-  f32x4 v[NV];
+  const int c = threadIdx.x * 4;
+  const bool live = c < D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    v = ldg4(bias + c);
+    for (int k0 = 0; k0 < K; k0 += KT) {
+      f32x4 zz[KT], ww[KT];
+      float on[KT];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    v[i] = (c < D) ? ldg4(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // taps in chunks of 5: all loads of a chunk are issued before its FMAs (edge taps read a clamped row
-  // and are multiplied by 0 = the conv's zero padding), so a frame costs ~3 memory round trips, not K
-  for (int k0 = 0; k0 < K; k0 += 5) {
-    f32x4 zz[5][NV], ww[5][NV];
-    float on[5];
-#pragma unroll
-    for (int kk = 0; kk < 5; ++kk) {
-      const int k = min(k0 + kk, K - 1);
-      const int tt = t + k - pad;
-      on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
-      const float* zr = z + ((size_t)b * T + min(max(tt, 0), T - 1)) * D;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-          zz[kk][i] = ldg4(zr + c);
-          ww[kk][i] = ldg4(w_kc + (size_t)k * D + c);
-        }
+      for (int kk = 0; kk < KT; ++kk) {
+        const int k = min(k0 + kk, K - 1);
+        const int tt = t + k - pad;
+        on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
+        zz[kk] = ldg4(z + ((size_t)b * T + min(max(tt, 0), T - 1)) * D + c);
+        ww[kk] = ldg4(w_kc + (size_t)k * D + c);
       }
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(zz[kk][j] * on[kk], ww[kk][j], v[j]);
     }
-#pragma unroll
-    for (int kk = 0; kk < 5; ++kk)
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if ((lane + 64 * i) * 4 < D) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[i][j] = fmaf(zz[kk][i][j] * on[kk], ww[kk][i][j], v[i][j]);
-        }
   }
-  float mean = 0.f, rstd = 1.f;
   if (gamma != nullptr) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if ((lane + 64 * i) * 4 < D) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    mean = wave_sum(s) / (float)D;
+    float s = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot += red[0][w];
+    const float mean = tot / (float)D;
     float q = 0.f;
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if ((lane + 64 * i) * 4 < D) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = v[i][j] - mean;
-          q += d * d;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[j] - mean;
+        q += d * d;
       }
-    rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    if (c < D) {
-      f32x4 o = v[i];
-      if (gamma != nullptr) {
-        const f32x4 g = ldg4(gamma + c), be = ldg4(beta + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (o[j] - mean) * rstd * g[j] + be[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = silu(o[j]);
-      stg4(out + (size_t)row * D + c, o);
     }
+    q = wave_sum(q);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    float qt = 0.f;
+    for (int w = 0; w < nwaves; ++w) qt += red[1][w];
+    const float rstd = rsqrtf(qt / (float)D + eps);
+    if (live) {
+      const f32x4 g = ldg4(gamma + c), be = ldg4(beta + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) * rstd * g[j] + be[j];
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+    stg4(out + (size_t)row * D + c, v);
   }
 }
 
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream) {
-  M3_REQUIRE((D & 3) == 0 && D <= 2048, "dwconv: channels=%d must be a multiple of 4 (<=2048)", D);
+  M3_REQUIRE((D & 3) == 0 && D <= 4096, "dwconv: channels=%d must be a multiple of 4 (<=4096)", D);
   M3_REQUIRE((K & 1) == 1, "dwconv: kernel size %d must be odd (non-causal)", K);
   const int rows = B * T;
   if (rows == 0) return 0;
-  const int nv = cdiv(D, 256);
-  dim3 grid(cdiv(rows, 4));
-#define M3_DW_CASE(NV_)                                                                                          \
-  hipLaunchKernelGGL((dwconv_ln_silu_kernel<NV_>), grid, dim3(256), 0, stream, z, w_kc, bias, gamma, beta, eps, T, \
-                     D, K, out, rows)
-  if (nv <= 1) M3_DW_CASE(1); else if (nv <= 2) M3_DW_CASE(2); else if (nv <= 4) M3_DW_CASE(4); else M3_DW_CASE(8);
-#undef M3_DW_CASE
+  const int threads = (int)align_up(D / 4, 64);
+  if (K <= 15)
+    hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
+                       eps, T, D, K, out);
+  else
+    hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
+                       eps, T, D, K, out);
   M3_LAUNCH_CHECK();
   return 0;
 }

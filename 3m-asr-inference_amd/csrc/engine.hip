@@ -34,7 +34,7 @@ using namespace m3;
 namespace {
 
 struct Norm { const float* g = nullptr; const float* b = nullptr; };
-struct Lin { const float* w = nullptr; const float* b = nullptr; };
+struct Lin { const float* w = nullptr; const float* b = nullptr; const float* wsum = nullptr; const float* wbeta = nullptr; };
 
 struct BlockW {
   Norm n_ffm, n_mha, n_conv, n_ff, n_final, n_cnn;
@@ -111,18 +111,25 @@ bool load_lin(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n
   if (bias) GET(l->b, p + "bias", n_out);
   return true;
 }
+// Linear with a LayerNorm folded in (plan.py fold_layernorm): weight = W*gamma, bias = b + W.beta, wsum = rowsum(W*gamma)
+bool load_lin_ln(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n_in, bool wbeta, Lin* l) {
+  GET(l->w, p + "ln.weight", n_out * n_in);
+  GET(l->b, p + "ln.bias", n_out);
+  GET(l->wsum, p + "ln.wsum", n_out);
+  if (wbeta) GET(l->wbeta, p + "ln.wbeta", n_out);
+  return true;
+}
 
 bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, bool cnn_ln, bool moe, int De, BlockW* b) {
   const m3_engine_config& c = e->cfg;
-  if (!load_norm(e, p + "norm_ff_macaron.", D, &b->n_ffm) || !load_norm(e, p + "norm_mha.", D, &b->n_mha) ||
-      !load_norm(e, p + "norm_conv.", D, &b->n_conv) || !load_norm(e, p + "norm_ff.", D, &b->n_ff) ||
-      !load_norm(e, p + "norm_final.", D, &b->n_final))
-    return false;
-  if (!load_lin(e, p + "feed_forward_macaron.w_1.", F, D, true, &b->mac1) ||
+  // norm_ff_macaron / norm_mha / norm_conv (and norm_ff of dense blocks) have no tensor of their own: folded into weights
+  if (!load_norm(e, p + "norm_final.", D, &b->n_final)) return false;
+  if (moe && !load_norm(e, p + "norm_ff.", D, &b->n_ff)) return false;
+  if (!load_lin_ln(e, p + "feed_forward_macaron.w_1.", F, D, false, &b->mac1) ||
       !load_lin(e, p + "feed_forward_macaron.w_2.", D, F, true, &b->mac2) ||
-      !load_lin(e, p + "self_attn.qkv.", 3 * D, D, true, &b->qkv) ||
+      !load_lin_ln(e, p + "self_attn.qkv.", 3 * D, D, false, &b->qkv) ||
       !load_lin(e, p + "self_attn.linear_out.", D, D, true, &b->out) ||
-      !load_lin(e, p + "conv_module.pointwise_conv1.", 2 * D, D, true, &b->pw1) ||
+      !load_lin_ln(e, p + "conv_module.pointwise_conv1.", 2 * D, D, true, &b->pw1) ||
       !load_lin(e, p + "conv_module.pointwise_conv2.", D, D, true, &b->pw2))
     return false;
   GET(b->pos_u, p + "self_attn.pos_bias_u", D);
@@ -131,7 +138,7 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
   GET(b->dw_b, p + "conv_module.depthwise_conv.bias", D);
   if (cnn_ln && !load_norm(e, p + "conv_module.norm.", D, &b->n_cnn)) return false;
   if (!moe) {
-    if (!load_lin(e, p + "feed_forward.w_1.", F, D, true, &b->ff1) ||
+    if (!load_lin_ln(e, p + "feed_forward.w_1.", F, D, false, &b->ff1) ||
         !load_lin(e, p + "feed_forward.w_2.", D, F, true, &b->ff2))
       return false;
   } else {
@@ -142,7 +149,7 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
     const int64_t E = c.num_experts;
     GET(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
     GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
-    GET(b->ew2, p + "feed_forward.experts.w_2.weight", E * D * F);
+    GET(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
     GET(b->eb2, p + "feed_forward.experts.w_2.bias", E * D);
   }
   return true;
@@ -257,7 +264,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   {  // x += 0.5 * FFN_macaron(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.mac1.w; g.bias = w.mac1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
-    g.ln_gamma = w.n_ffm.g; g.ln_beta = w.n_ffm.b; g.ln_eps = eps; g.act = ACT_SILU;
+    g.ln_wsum = w.mac1.wsum; g.ln_eps = eps; g.act = ACT_SILU;   // norm_ff_macaron is folded into w_1 (plan.py)
     add_gemm(e, pfx + "ffn_macaron.w1", g);
     GemmParams h;
     h.A = pl.h1; h.lda = F; h.W = w.mac2.w; h.bias = w.mac2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
@@ -267,7 +274,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   {  // x += MHA(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.qkv.w; g.bias = w.qkv.b; g.Y = pl.qkv; g.ldy = 3 * D; g.M = S; g.N = 3 * D; g.K = D;
-    g.ln_gamma = w.n_mha.g; g.ln_beta = w.n_mha.b; g.ln_eps = eps;
+    g.ln_wsum = w.qkv.wsum; g.ln_eps = eps;                  // norm_mha is folded into the qkv weight
     add_gemm(e, pfx + "att.qkv", g);
     // p = linear_pos(pos_emb) of all blocks comes from ONE GEMM per forward ("pos_all" stage):
     // block i's slice is columns [i*D, (i+1)*D) of pbuf [T'][n_blocks*D]
@@ -288,7 +295,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   {  // x += ConvModule(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.pw1.w; g.bias = w.pw1.b; g.Y = pl.glu; g.ldy = D; g.M = S; g.N = 2 * D; g.K = D;
-    g.ln_gamma = w.n_conv.g; g.ln_beta = w.n_conv.b; g.ln_eps = eps; g.act = ACT_GLU;
+    g.ln_wsum = w.pw1.wsum; g.ln_wbeta = w.pw1.wbeta; g.ln_eps = eps; g.act = ACT_GLU;   // norm_conv folded into pw1
     g.row_len = lens; g.rows_per_batch = Tp; g.mask_in = 1;
     add_gemm(e, pfx + "conv.pw1_glu", g);
     const float* glu = pl.glu; float* dw = pl.dw;
@@ -305,7 +312,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   if (!moe) {  // x = LN_final(x + 0.5 * FFN(LN(x)))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.ff1.w; g.bias = w.ff1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
-    g.ln_gamma = w.n_ff.g; g.ln_beta = w.n_ff.b; g.ln_eps = eps; g.act = ACT_SILU;
+    g.ln_wsum = w.ff1.wsum; g.ln_eps = eps; g.act = ACT_SILU;   // norm_ff is folded into w_1
     add_gemm(e, pfx + "ffn.w1", g);
     GemmParams h;
     h.A = pl.h1; h.lda = F; h.W = w.ff2.w; h.bias = w.ff2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
@@ -327,20 +334,27 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // out once as xn, the expert FFN's input
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
     add_gemm(e, pfx + "moe_router", r);
-    add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
-      return launch_softmax_top1(rl, Etot, lens, Tp, S, Etot, gidx, gval, s);
-    });
     void* mws = (char*)pl.moe_ws + (c.debug_taps ? (size_t)layer * pl.moe_ws_bytes : 0);
     const MoeWorkspace mw = carve_moe_workspace(mws, S, E, D, F);
     const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     const float* gv = c.keep_expert_output ? nullptr : gval;
-    // the three "moe_local" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
-    add_stage(e, pfx + "moe_local.index", 1, [=](hipStream_t s) {
-      return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
-    });
+    // "moe_local.*" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
+    if (world == 1 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
+      // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch
+      add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
+        return launch_moe_gate_index(rl, Etot, lens, Tp, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
+      });
+    } else {
+      add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
+        return launch_softmax_top1(rl, Etot, lens, Tp, S, Etot, gidx, gval, s);
+      });
+      add_stage(e, pfx + "moe_local.index", 1, [=](hipStream_t s) {
+        return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
+      });
+    }
     add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
-      return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, mw.slab, s);
+      return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
     });
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(mw.slab, F / kExpertSlice, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
@@ -393,8 +407,8 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   const int D = c.attention_dim, De = c.embed_dim, K = c.cnn_module_kernel;
   if (!load_sub(e, "embed.subsampling.", De, c.input_dim, &e->sub_e) || !load_sub(e, "subsampling.", D, c.input_dim, &e->sub_m))
     return fail(nullptr);
-  if (!load_norm(e, "embed.after_norm.", De, &e->e_after) || !load_norm(e, "after_norm.", D, &e->m_after) ||
-      !load_lin(e, "out_linear.", c.output_dim, D, true, &e->out_linear))
+  if (!load_norm(e, "embed.after_norm.", De, &e->e_after) ||
+      !load_lin_ln(e, "out_linear.", c.output_dim, D, false, &e->out_linear))
     return fail(nullptr);
   {
     auto it = e->table.find("pe");
@@ -480,7 +494,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams g;
     g.A = pl.x; g.lda = D; g.W = e->out_linear.w; g.bias = e->out_linear.b; g.Y = logits; g.ldy = c.output_dim;
     g.M = S; g.N = c.output_dim; g.K = D;
-    g.ln_gamma = e->m_after.g; g.ln_beta = e->m_after.b; g.ln_eps = 1e-12f;
+    g.ln_wsum = e->out_linear.wsum; g.ln_eps = 1e-12f;       // after_norm is folded into out_linear
     add_gemm(e, "logits", g);
   }
   e->buffers["x"] = Buf{pl.x, (size_t)S * D * 4};

@@ -6,31 +6,55 @@
 //   Conv2d 3x3 stride 2 (second subsampling conv)  (torch_network_helper.py:227-251) as implicit GEMM
 //   router matmul on cat([embed, x])               (trainer_3m_fix/layer/positionwise_feed_forward.py:169-180,225)
 // with the surrounding element-wise layers fused as prologue / epilogue:
-//   LayerNorm on the A rows (layer_norm_kernel.cu:33-139, but WITH eps, two-pass variance),
+//   LayerNorm on the A rows (layer_norm_kernel.cu:33-139, but WITH eps),
 //   masked_fill(0) of padded frames before / after (masked_fill_kernel.cu:27-54),
 //   bias, ReLU / SiLU / GLU (glu_kernel.cu:26-44), uniform scale + residual add
 //   (tensor_network_helper.py:406-471).
 //
 // Shape regime: M = B*T' tokens (50 .. ~2000), N, K in 512..4608: every weight element is used by
-// only M rows, so this is a weight-streaming, latency-sensitive kernel.  One workgroup = 16 output
-// columns (x2 for GLU) x 16*MT rows; its 4 waves split K round-robin in 16-deep steps; each wave
-// streams its W rows and A rows straight into VGPRs (float4 per lane = 16 rows x 64 B per
-// instruction), two groups of G steps in flight; partial tiles are summed through LDS in a fixed
-// order (no atomics -> bitwise reproducible).  Small M is split into 16-row tiles (MT = 1) so a
-// 50-token utterance still spreads over 128-384 workgroups; the tiles of one weight column block
-// are placed on the same XCD (blockIdx % 8) so the weight tile is fetched from HBM once.
+// only M rows, so this is a weight-streaming kernel whose run time at M = 50 is a few microseconds,
+// i.e. it is bound by memory latency and by the number of instructions a wave issues.  Layout:
+// one workgroup = 16 output columns (x2 for GLU) x 16*MT rows; its NW waves split K round-robin in
+// 16-deep steps; each wave streams its W rows and A rows straight into VGPRs (float4 per lane = 16
+// rows x 64 B per instruction), two groups of G steps in flight, all loads unconditional (clamped
+// addresses: a branch around a load makes hipcc wait per load); partial tiles are summed through LDS in
+// a fixed order (no atomics -> bitwise reproducible).  Small M is split into 16-row tiles so a
+// 50-token utterance spreads over 128-256 workgroups; the tiles of one weight column block sit on
+// the same XCD (blockIdx % 8) so the weight tile is fetched from HBM once.
+//
+// LayerNorm has two forms:
+//  * LN_EPI (engine): the affine is folded into W / bias when the plan is packed, and the
+//    normalisation moves to the OUTPUT side:  y_n = rstd_m * (acc_mn - mean_m * wsum_n) + bias'_n  with
+//    wsum_n = sum_k W'_nk.  The GEMM runs on the raw rows, the row sums (sum a, sum a^2) are taken from
+//    the A fragments already in registers, so LayerNorm costs no extra memory round trip and no barrier.
+//  * LN_PRO (generic m3_linear with gamma / beta): statistics (two-pass) + affine applied to the A
+//    fragments before the MFMAs; can also write the normalised rows out (ln_out).
 #include "common.h"
 #include "kernels.h"
 
 namespace m3 {
 
-template <int MT, bool GLU>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+// K-steps per in-flight load group: 2 buffers x G x (NT + MT) float4 must fit the per-lane register
+// budget (512 VGPR+AGPR for 4 waves, 256 for 8, 128 for 16 waves per workgroup) without spilling.
+constexpr int gemm_group_steps(int MT, int NT, int NW) {
+  if (NW == 16) return MT == 1 ? (NT == 1 ? 4 : 2) : (MT == 2 ? 2 : 1);
+  if (NW == 8) return MT == 1 ? 8 : (MT == 2 ? (NT == 1 ? 6 : 4) : (NT == 1 ? 3 : 2));
+  return MT == 1 ? 8 : (MT == 2 ? 6 : 4);
+}
+
+enum { LN_NONE = 0, LN_EPI = 1, LN_PRO = 2 };
+
+// NW = waves per workgroup = K-split factor (4 / 8 / 16 for K ~ 512 / 1024 / >= 2048).
+template <int MT, bool GLU, int NW, bool CONV, int LN>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   constexpr int NT = GLU ? 2 : 1;
-  constexpr int G = MT == 1 ? 8 : (MT == 2 ? 6 : 4);  // K-steps per in-flight group
-  constexpr int RW = 4 * MT;                          // rows per wave in the LayerNorm prologue
-  __shared__ float red[4][MT * NT][256];
+  constexpr int G = gemm_group_steps(MT, NT, NW);
+  constexpr int RW = (16 * MT) / NW;   // rows per wave in the LN_PRO prologue (>= 1)
+  static_assert(RW >= 1, "more waves than rows");
+  __shared__ float red[NW][MT * NT][256];
   __shared__ float stats[16 * MT][2];
+  __shared__ float rsum[LN == LN_EPI ? NW : 1][16 * MT][2];
+  __shared__ __attribute__((aligned(16))) float ln_g[LN == LN_PRO ? 1024 : 4], ln_b[LN == LN_PRO ? 1024 : 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
@@ -51,68 +75,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   }
   const int n0 = n_tile * 16;
   const int m0 = m_tile * (16 * MT);
+  const int ln_k0 = p.ln_on_a2 ? p.K1 : 0;             // first K index the LayerNorm applies to
+  const int Kl = p.K - ln_k0;                          // LayerNorm row width
 
-  // ---- optional LayerNorm statistics of this workgroup's A rows: all rows of a wave in flight ----
-  if (p.ln_gamma != nullptr) {
-    const float* lnA = p.ln_on_a2 ? p.A2 : p.A;
-    const int ldl = p.ln_on_a2 ? p.lda2 : p.lda;
-    const int Kl = p.ln_on_a2 ? (p.K - p.K1) : p.K;
-    const int nv = (Kl + 255) >> 8;                    // float4 per lane per row (<= 4 -> K <= 1024)
-    for (int c = 0; c < MT; ++c) {                     // 4 rows of this wave at a time, all loads in flight
-      f32x4 v[4][4];
-      float s[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = min(m0 + wave * RW + 4 * c + r, p.M - 1);
-        const float* row = lnA + (size_t)m * ldl;
-        s[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = (lane + 64 * i) * 4;
-          v[r][i] = (i < nv && k < Kl) ? ldg4(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
-        s[r] = wave_sum(s[r]) / (float)Kl;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = (lane + 64 * i) * 4;
-          if (i < nv && k < Kl) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float d = v[r][i][j] - s[r];
-              q += d * d;
-            }
-          }
-        }
-        q = wave_sum(q) / (float)Kl;
-        if (lane == 0) {
-          stats[wave * RW + 4 * c + r][0] = s[r];
-          stats[wave * RW + 4 * c + r][1] = rsqrtf(q + p.ln_eps);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- per-lane A row descriptors ----
+  // ---- per-lane row descriptors ----
   const float* arow[MT];
   const float* arow2[MT];
-  float a_mean[MT], a_rstd[MT];
   bool a_zero[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = min(m0 + 16 * mt + col, p.M - 1);
     a_zero[mt] = false;
     arow2[mt] = nullptr;
-    if (p.mode == GEMM_A_CONV3X3S2) {
+    if (CONV) {
       const int f2 = m % p.conv_F2;
       const int t2 = (m / p.conv_F2) % p.conv_T2;
       const int b = m / (p.conv_F2 * p.conv_T2);
@@ -121,14 +96,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
       arow[mt] = p.A + (size_t)m * p.lda + 4 * kq;
       if (p.mode == GEMM_A_CONCAT2) arow2[mt] = p.A2 + (size_t)m * p.lda2 + 4 * kq;
     }
-    if (p.mask_in) {
-      const int b = m / p.rows_per_batch, t = m % p.rows_per_batch;
-      a_zero[mt] = t >= p.row_len[b];
-    }
-    if (p.ln_gamma != nullptr) {
-      a_mean[mt] = stats[16 * mt + col][0];
-      a_rstd[mt] = stats[16 * mt + col][1];
-    }
+    if (p.mask_in) a_zero[mt] = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
   }
   const float* wrow[NT];
 #pragma unroll
@@ -140,19 +108,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[MT], s2[MT];   // LN_EPI: this lane's share of sum(a), sum(a^2) of row (16*mt + col)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) s1[mt] = s2[mt] = 0.f;
 
   const int nsteps = p.K >> 4;
-  const int ln_k0 = p.ln_on_a2 ? p.K1 : 0;             // first K index the LayerNorm applies to
-  float* ln_out_row[MT];                               // side output of the normalised rows (router fusion)
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + 16 * mt + col;
-    ln_out_row[mt] = (p.ln_out != nullptr && n_tile == 0 && m < p.M) ? p.ln_out + (size_t)m * p.ld_ln_out + 4 * kq
-                                                                      : nullptr;
-  }
-
   auto a_offset = [&](int k) -> int {  // wave-uniform k (multiple of 16) -> element offset in the A row
-    if (p.mode == GEMM_A_CONV3X3S2) {
+    if (CONV) {
       const int seg = k / p.conv_C, c = k - seg * p.conv_C;
       const int kh = seg / 3, kw = seg - kh * 3;
       return (kh * p.conv_F1 + kw) * p.conv_C + c;
@@ -165,41 +127,135 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   auto load_group = [&](int g, int buf) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-      const int s = wave + 4 * (G * g + i);
-      if (s < nsteps) {
-        const int k = s << 4;
+      // steps past the end re-load the last step (results unused): no branch around the loads
+      const int s = min(wave + NW * (G * g + i), nsteps - 1);
+      const int k = s << 4;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg4(wrow[t] + k);
-        if (p.mode == GEMM_A_CONCAT2 && k >= p.K1) {
+      for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg4(wrow[t] + k);
+      const bool second = !CONV && p.mode == GEMM_A_CONCAT2 && k >= p.K1;
+      const int off = second ? (k - p.K1) : a_offset(k);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) abuf[buf][i][mt] = ldg4(arow2[mt] + (k - p.K1));
-        } else {
-          const int off = a_offset(k);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) abuf[buf][i][mt] = ldg4(arow[mt] + off);
-        }
-      }
+      for (int mt = 0; mt < MT; ++mt) abuf[buf][i][mt] = ldg4((second ? arow2[mt] : arow[mt]) + off);
     }
   };
+
+  // the epilogue wave's bias / residual are requested up front (they would otherwise be a dependent
+  // memory round trip at the very end of a microsecond-scale kernel)
+  const int ep_mt = wave;              // wave w finishes row sub-tile w (w < MT)
+  const bool is_ep = wave < MT;
+  const int ep_n = n0 + col;
+  float bias0 = 0.f, bias1 = 0.f, wsum0 = 0.f, wsum1 = 0.f, wbeta0 = 0.f, wbeta1 = 0.f, res[4] = {0.f, 0.f, 0.f, 0.f};
+  if (is_ep && ep_n < Nout) {
+    if (p.bias) {
+      bias0 = p.bias[ep_n];
+      if (GLU) bias1 = p.bias[ep_n + Nout];
+    }
+    if (LN == LN_EPI) {
+      wsum0 = p.ln_wsum[ep_n];
+      if (GLU) wsum1 = p.ln_wsum[ep_n + Nout];
+      if (p.mask_in) {
+        wbeta0 = p.ln_wbeta[ep_n];
+        if (GLU) wbeta1 = p.ln_wbeta[ep_n + Nout];
+      }
+    }
+    if (p.resid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(m0 + 16 * ep_mt + 4 * kq + r, p.M - 1);
+        res[r] = p.resid[(size_t)m * p.ldr + ep_n];
+      }
+    }
+  }
+
+  const int ngroups = (nsteps + NW * G - 1) / (NW * G);
+  load_group(0, 0);
+
+  // ---- LN_PRO: row statistics (two-pass) + gamma/beta to LDS, while the first loads are in flight ----
+  float a_mean[MT], a_rstd[MT];
+  float* ln_out_row[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    a_mean[mt] = 0.f;
+    a_rstd[mt] = 1.f;
+    ln_out_row[mt] = nullptr;
+  }
+  if (LN == LN_PRO) {
+    const float* lnA = p.ln_on_a2 ? p.A2 : p.A;
+    const int ldl = p.ln_on_a2 ? p.lda2 : p.lda;
+    for (int k = threadIdx.x * 4; k < Kl; k += 256 * NW) {
+      *reinterpret_cast<f32x4*>(&ln_g[k]) = ldg4(p.ln_gamma + k);
+      *reinterpret_cast<f32x4*>(&ln_b[k]) = ldg4(p.ln_beta + k);
+    }
+    // one 16-lane row group per A row (4 rows per wave pass): 256 B of a row per load instruction
+    const int q = lane >> 4, l16 = lane & 15;
+    const int nj = (Kl + 63) >> 6;                     // float4 per lane per row (<= 16 -> rows up to 1024 wide)
+    for (int c = 0; c < (RW + 3) / 4; ++c) {
+      const int rloc = wave * RW + 4 * c + q;
+      const bool row_on = (4 * c + q) < RW;
+      const int m = min(m0 + min(rloc, 16 * MT - 1), p.M - 1);
+      const float* row = lnA + (size_t)m * ldl;
+      f32x4 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = 4 * (l16 + 16 * j);
+        const f32x4 t = ldg4(row + min(k, Kl - 4));
+        const bool in = j < nj && k < Kl;
+        v[j] = f32x4{in ? t[0] : 0.f, in ? t[1] : 0.f, in ? t[2] : 0.f, in ? t[3] : 0.f};
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+      const float mean = group16_sum(sum) / (float)Kl;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = 4 * (l16 + 16 * j);
+        const float on = (j < nj && k < Kl) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = (v[j][e] - mean) * on;
+          sq += d * d;
+        }
+      }
+      const float var = group16_sum(sq) / (float)Kl;
+      if (row_on && l16 == 0) {
+        stats[rloc][0] = mean;
+        stats[rloc][1] = rsqrtf(var + p.ln_eps);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      a_mean[mt] = stats[16 * mt + col][0];
+      a_rstd[mt] = stats[16 * mt + col][1];
+      const int m = m0 + 16 * mt + col;
+      if (p.ln_out != nullptr && n_tile == 0 && m < p.M) ln_out_row[mt] = p.ln_out + (size_t)m * p.ld_ln_out + 4 * kq;
+    }
+  }
+
   auto compute_group = [&](int g, int buf) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-      const int s = wave + 4 * (G * g + i);
+      const int s = wave + NW * (G * g + i);
       if (s < nsteps) {
         const int k = s << 4;
-        const bool do_ln = p.ln_gamma != nullptr && k >= ln_k0;
+        const bool in_ln = k >= ln_k0;
         f32x4 g4, b4;
-        if (do_ln) {
-          g4 = ldg4(p.ln_gamma + (k - ln_k0) + 4 * kq);
-          b4 = ldg4(p.ln_beta + (k - ln_k0) + 4 * kq);
+        if (LN == LN_PRO && in_ln) {
+          g4 = *reinterpret_cast<const f32x4*>(&ln_g[(k - ln_k0) + 4 * kq]);
+          b4 = *reinterpret_cast<const f32x4*>(&ln_b[(k - ln_k0) + 4 * kq]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           f32x4 a = abuf[buf][i][mt];
-          if (do_ln) {
+          if (LN == LN_PRO && in_ln) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = (a[j] - a_mean[mt]) * a_rstd[mt] * g4[j] + b4[j];
             if (ln_out_row[mt] != nullptr) stg4(ln_out_row[mt] + (k - ln_k0), a);
+          }
+          if (LN == LN_EPI && in_ln) {
+            s1[mt] += (a[0] + a[1]) + (a[2] + a[3]);
+            s2[mt] += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
           }
           if (a_zero[mt]) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -211,8 +267,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
   };
 
-  const int ngroups = (nsteps + 4 * G - 1) / (4 * G);
-  load_group(0, 0);
   for (int g = 0; g < ngroups; g += 2) {
     if (g + 1 < ngroups) load_group(g + 1, 1);
     compute_group(g, 0);
@@ -222,42 +276,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
   }
 
-  // ---- cross-wave K reduction through LDS, then epilogue (wave w finishes tiles w, w+4, ..) ----
+  // ---- cross-wave K reduction through LDS, then epilogue (wave w finishes row sub-tile w) ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][mt * NT + t][r * 64 + lane] = acc[mt][t][r];
+  if (LN == LN_EPI) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float a1 = s1[mt], a2 = s2[mt];           // fold the 4 k-quarters of this wave (lanes col, col+16, +32, +48)
+      a1 += __shfl_xor(a1, 16, 64);
+      a2 += __shfl_xor(a2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 32, 64);
+      if (kq == 0) {
+        rsum[wave][16 * mt + col][0] = a1;
+        rsum[wave][16 * mt + col][1] = a2;
+      }
+    }
+  }
   __syncthreads();
 
-  for (int mt = wave; mt < MT; mt += 4) {
+  if (is_ep) {
+    const int mt = ep_mt;
     f32x4 v[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        v[t][r] = (red[0][mt * NT + t][r * 64 + lane] + red[1][mt * NT + t][r * 64 + lane]) +
-                  (red[2][mt * NT + t][r * 64 + lane] + red[3][mt * NT + t][r * 64 + lane]);
-    const int n = n0 + col;
-    if (n >= Nout) continue;
-    const float bias0 = p.bias ? p.bias[n] : 0.f;
-    const float bias1 = (GLU && p.bias) ? p.bias[n + Nout] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;   // fixed summation order over the K-split -> bitwise reproducible
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * mt + 4 * kq + r;
-      if (m >= p.M) continue;
-      float y = v[0][r] + bias0;
-      if (GLU) y = y * sigmoidf(v[NT - 1][r] + bias1);
-      if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
-      if (p.act == ACT_SILU) y = silu(y);
-      if (p.mask_out) {
-        const int b = m / p.rows_per_batch, t = m % p.rows_per_batch;
-        if (t >= p.row_len[b]) y = 0.f;
+        for (int w = 0; w < NW; w += 4)
+          sum += (red[w][mt * NT + t][r * 64 + lane] + red[w + 1][mt * NT + t][r * 64 + lane]) +
+                 (red[w + 2][mt * NT + t][r * 64 + lane] + red[w + 3][mt * NT + t][r * 64 + lane]);
+        v[t][r] = sum;
       }
-      y *= p.alpha;
-      if (p.resid) y += p.resid[(size_t)m * p.ldr + n];
-      p.Y[(size_t)m * p.ldy + n] = y;
+    if (ep_n < Nout) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + 4 * kq + r;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float y0 = v[0][r], y1 = v[NT - 1][r];
+        bool pad = false;
+        if (p.mask_in || p.mask_out) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+        if (LN == LN_EPI) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            t1 += rsum[w][row][0];
+            t2 += rsum[w][row][1];
+          }
+          const float mean = t1 / (float)Kl;
+          const float var = fmaxf(t2 / (float)Kl - mean * mean, 0.f);
+          const float rstd = rsqrtf(var + p.ln_eps);
+          if (p.mask_in && pad) {   // masked_fill(0) after the LayerNorm: the row contributes the plain bias only
+            y0 = -wbeta0;
+            y1 = -wbeta1;
+          } else {
+            y0 = rstd * (y0 - mean * wsum0);
+            y1 = rstd * (y1 - mean * wsum1);
+          }
+        }
+        float y = y0 + bias0;
+        if (GLU) y = y * sigmoidf(y1 + bias1);
+        if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+        if (p.act == ACT_SILU) y = silu(y);
+        if (p.mask_out && pad) y = 0.f;
+        y *= p.alpha;
+        if (p.resid) y += res[r];
+        p.Y[(size_t)m * p.ldy + ep_n] = y;
+      }
     }
   }
 }
@@ -269,33 +360,63 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   M3_REQUIRE((p.lda & 3) == 0, "gemm: lda=%d must be a multiple of 4", p.lda);
   const bool glu = p.act == ACT_GLU;
   M3_REQUIRE(!glu || (p.N & 1) == 0, "gemm: GLU needs even N");
+  const bool conv = p.mode == GEMM_A_CONV3X3S2;
   if (p.mode == GEMM_A_CONCAT2)
     M3_REQUIRE((p.K1 & 15) == 0 && p.A2 != nullptr && (p.lda2 & 3) == 0, "gemm: bad concat operands");
-  if (p.mode == GEMM_A_CONV3X3S2)
-    M3_REQUIRE((p.conv_C & 15) == 0 && p.K == 9 * p.conv_C, "gemm: conv mode needs K=9*C, C%%16==0");
-  if (p.ln_gamma) {
+  if (conv) M3_REQUIRE((p.conv_C & 15) == 0 && p.K == 9 * p.conv_C, "gemm: conv mode needs K=9*C, C%%16==0");
+  const int ln = p.ln_wsum ? LN_EPI : (p.ln_gamma ? LN_PRO : LN_NONE);
+  M3_REQUIRE(!(p.ln_wsum && p.ln_gamma), "gemm: folded (ln_wsum) and affine (ln_gamma) LayerNorm are exclusive");
+  if (ln != LN_NONE) {
     M3_REQUIRE(p.mode == GEMM_A_PLAIN || (p.mode == GEMM_A_CONCAT2 && p.ln_on_a2),
-               "gemm: LN prologue needs plain A (or the A2 half of a concat)");
-    M3_REQUIRE((p.ln_on_a2 ? p.K - p.K1 : p.K) <= 1024, "gemm: LN prologue supports rows up to 1024 wide");
+               "gemm: LayerNorm needs plain A (or the A2 half of a concat)");
+    M3_REQUIRE((p.ln_on_a2 ? p.K - p.K1 : p.K) <= 1024, "gemm: LayerNorm supports rows up to 1024 wide");
+    M3_REQUIRE(p.K <= 2047, "gemm: LayerNorm variants are built for K < 2048");
   }
   M3_REQUIRE(!p.ln_on_a2 || p.mode == GEMM_A_CONCAT2, "gemm: ln_on_a2 needs concat mode");
-  M3_REQUIRE(p.ln_out == nullptr || p.ln_gamma != nullptr, "gemm: ln_out needs the LN prologue");
+  M3_REQUIRE(p.ln_out == nullptr || ln == LN_PRO, "gemm: ln_out needs the affine LayerNorm prologue");
+  M3_REQUIRE(!(ln == LN_EPI && p.mask_in) || p.ln_wbeta, "gemm: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm: mask needs row_len");
   const int Nout = glu ? p.N / 2 : p.N;
-  // row tile: 16*MT rows per workgroup; short inputs are cut into 16-row tiles to fill the chip
-  const int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
+  // row tile: 16*MT rows per workgroup; short inputs are cut into 16-row tiles to fill the chip, but more
+  // workgroups than fit at once (2 per CU) only serialise: then prefer fatter tiles
+  int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
+  while (mt < 4 && 16 * mt < p.M && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) > 512) mt *= 2;
   p.n_tiles = cdiv(Nout, 16);
   p.m_tiles = cdiv(p.M, 16 * mt);
   p.xcd_swizzle = (p.n_tiles % 8 == 0) ? 1 : 0;
   dim3 grid(p.n_tiles * p.m_tiles);
-#define M3_GEMM_CASE(MT_, GLU_)                                                          \
-  hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_>), grid, dim3(256), 0, stream, p)
-  if (glu) {
-    if (mt == 1) M3_GEMM_CASE(1, true); else if (mt == 2) M3_GEMM_CASE(2, true); else M3_GEMM_CASE(4, true);
+  int nw = p.K >= 2048 ? 16 : (p.K >= 1024 ? 8 : 4);
+  if (nw == 16 && (glu || mt == 4)) nw = 8;   // those 16-wave variants would spill registers
+  if (nw == 16 && ln != LN_NONE) nw = 8;
+
+#define M3_GEMM_LAUNCH(MT_, GLU_, NW_, CONV_, LN_) \
+  hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_, NW_, CONV_, LN_>), grid, dim3(64 * NW_), 0, stream, p)
+#define M3_GEMM_MT(GLU_, NW_, CONV_, LN_)                                                              \
+  do {                                                                                                 \
+    if (mt == 1) M3_GEMM_LAUNCH(1, GLU_, NW_, CONV_, LN_);                                             \
+    else if (mt == 2) M3_GEMM_LAUNCH(2, GLU_, NW_, CONV_, LN_);                                        \
+    else M3_GEMM_LAUNCH(4, GLU_, NW_, CONV_, LN_);                                                     \
+  } while (0)
+#define M3_GEMM_LN(GLU_, NW_)                                                                          \
+  do {                                                                                                 \
+    if (ln == LN_EPI) M3_GEMM_MT(GLU_, NW_, false, LN_EPI);                                            \
+    else if (ln == LN_PRO) M3_GEMM_MT(GLU_, NW_, false, LN_PRO);                                       \
+    else M3_GEMM_MT(GLU_, NW_, false, LN_NONE);                                                        \
+  } while (0)
+  if (conv) {                       // implicit 3x3 conv: no GLU, no LayerNorm
+    M3_REQUIRE(!glu && ln == LN_NONE, "gemm: conv mode supports neither GLU nor LayerNorm");
+    if (nw == 16) M3_GEMM_MT(false, 16, true, LN_NONE); else if (nw == 8) M3_GEMM_MT(false, 8, true, LN_NONE);
+    else M3_GEMM_MT(false, 4, true, LN_NONE);
+  } else if (nw == 16) {            // K >= 2048: plain only
+    M3_GEMM_MT(false, 16, false, LN_NONE);
+  } else if (glu) {
+    if (nw == 8) M3_GEMM_LN(true, 8); else M3_GEMM_LN(true, 4);
   } else {
-    if (mt == 1) M3_GEMM_CASE(1, false); else if (mt == 2) M3_GEMM_CASE(2, false); else M3_GEMM_CASE(4, false);
+    if (nw == 8) M3_GEMM_LN(false, 8); else M3_GEMM_LN(false, 4);
   }
-#undef M3_GEMM_CASE
+#undef M3_GEMM_LN
+#undef M3_GEMM_MT
+#undef M3_GEMM_LAUNCH
   M3_LAUNCH_CHECK();
   return 0;
 }

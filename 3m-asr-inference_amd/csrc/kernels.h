@@ -19,6 +19,8 @@ struct GemmParams {
   int mode = GEMM_A_PLAIN;
   // prologue
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 0.f;
+  // folded LayerNorm (affine already inside W / bias): wsum[n] = sum_k W'[n][k]; wbeta[n] = (W . beta)[n] (only with mask_in)
+  const float* ln_wsum = nullptr; const float* ln_wbeta = nullptr;
   int ln_on_a2 = 0;                                       // CONCAT2: LayerNorm only the A2 half (router input)
   float* ln_out = nullptr; int ld_ln_out = 0;             // optional side output of the normalised rows
   const int32_t* row_len = nullptr; int rows_per_batch = 0;  // frame t = row % rows_per_batch is padded if t >= row_len[row / rows_per_batch]
@@ -37,6 +39,10 @@ int launch_gemm_f32(const GemmParams& p, hipStream_t stream);
 // ---- MoE indexing / scatter / gather (moe_index.hip) ----
 int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist,
                      int32_t* pos, hipStream_t stream);
+// SoftmaxTopK + ScatterMapping fused (router logits [S][width] -> gate_idx, gate_value, mapping, acc, pos)
+int launch_moe_gate_index(const float* logits, int width, const int32_t* row_len, int rows_per_batch, int S,
+                          int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
+                          hipStream_t stream);
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 
@@ -45,7 +51,7 @@ constexpr int kExpertSlice = 64;  // hidden units per workgroup
 size_t expert_ffn_slab_bytes(int S, int D, int F);
 int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
-                          int D, int F, const float* w1, const float* b1, const float* w2, float* slab,
+                          int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
                           hipStream_t stream);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,

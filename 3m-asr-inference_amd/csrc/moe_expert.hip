@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
                                                              const int32_t* __restrict__ acc_hist, int S, int D,
                                                              int F, const float* __restrict__ w1,
                                                              const float* __restrict__ b1,
-                                                             const float* __restrict__ w2,
-                                                             float* __restrict__ slab) {
+                                                             const float* __restrict__ w2, int w2_row_stride,
+                                                             int w2_slice_stride, float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int e = blockIdx.y, slice = blockIdx.x;
   const int row_lo = acc_hist[e], row_hi = acc_hist[e + 1];
@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
   const float* w1row = w1 + ((size_t)e * F + f0 + 16 * wave + col) * D + 4 * kq;
   const float bias1 = b1[(size_t)e * F + f0 + 16 * wave + col];
   const int nsub = D >> 4;                   // 16-column output tiles of phase 2
+  // W2[e][:, slice]: reference layout [E][D][F] (row stride F, slices 64 floats apart) or the plan's
+  // slice-major repack [E][F/64][D][64] (row stride 64: the workgroup's 128 KB are contiguous)
+  const float* w2_slice = w2 + (size_t)e * D * F + (size_t)slice * w2_slice_stride;
 
   // One stream of weight loads per wave: g1 groups of 8 W1 k-steps, then g2 groups of 2 W2 tiles
   // (8 float4 each), double-buffered so 8-16 float4 per lane stay in flight across the phase change.
@@ -63,18 +66,16 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
       if (g < g1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int s = 8 * g + i;
-          if (s < ksteps1) wb[buf][i] = ldg4(w1row + (s << 4));
+          const int s = min(8 * g + i, ksteps1 - 1);   // clamped, not branched: loads stay back to back
+          wb[buf][i] = ldg4(w1row + (s << 4));
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int sub = wave + 4 * (2 * (g - g1) + j);
-          if (sub < nsub) {
-            const float* p = w2 + ((size_t)e * D + 16 * sub + col) * F + f0 + 4 * kq;
+          const int sub = min(wave + 4 * (2 * (g - g1) + j), nsub - 1);
+          const float* p = w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 4 * kq;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) wb[buf][4 * j + st] = ldg4(p + 16 * st);
-          }
+          for (int st = 0; st < 4; ++st) wb[buf][4 * j + st] = ldg4(p + 16 * st);
         }
       }
     };
@@ -180,7 +181,7 @@ size_t expert_ffn_slab_bytes(int S, int D, int F) {
 }
 
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
-                          int F, const float* w1, const float* b1, const float* w2, float* slab,
+                          int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
                           hipStream_t stream) {
   M3_REQUIRE(S > 0 && E > 0, "expert_ffn: empty problem S=%d E=%d", S, E);
   M3_REQUIRE((D & 15) == 0 && D <= 2048, "expert_ffn: idim=%d must be a multiple of 16 (<=2048)", D);
@@ -191,10 +192,12 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(float);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn: LDS tile of %zu bytes does not fit", lds_bytes);
   dim3 grid(F / kExpertSlice, E);
+  const int w2_row_stride = w2_sliced ? kExpertSlice : F;
+  const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
   if (int rc = init_expert_ffn_kernels()) return rc;
 #define M3_EXPERT_CASE(MT_)                                                                             \
   hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(256), lds_bytes, stream, x, ldx, pos,    \
-                     acc_hist, S, D, F, w1, b1, w2, slab)
+                     acc_hist, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
 #undef M3_EXPERT_CASE
   M3_LAUNCH_CHECK();

@@ -31,9 +31,51 @@ __device__ __forceinline__ unsigned long long match_expert(int key, bool active,
   return active ? mask : 0ull;
 }
 
-__global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* __restrict__ gate, int S, int E, int nbits,
+// Router gate on one lane: softmax + top-1 over WIDTH logits with the reference's arg-max tree
+// (SoftmaxAndTop1KernelSmall, softmax_topk_kernel.cu:55-64: stride tree, strict '<').
+template <int WIDTH>
+__device__ __forceinline__ void gate_top1_lane(const float* __restrict__ row, int* idx_out, float* val_out) {
+  constexpr int H = WIDTH / 2;
+  float v[H];
+  int id[H];
+  // first tree stage (stride WIDTH/2) while loading, so only WIDTH/2 candidates stay in registers
+#pragma unroll
+  for (int j = 0; j < H; j += 4) {
+    const f32x4 lo = ldg4(row + j), hi = ldg4(row + H + j);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool take_hi = lo[q] < hi[q];
+      v[j + q] = take_hi ? hi[q] : lo[q];
+      id[j + q] = take_hi ? H + j + q : j + q;
+    }
+  }
+#pragma unroll
+  for (int stride = H >> 1; stride > 0; stride >>= 1)
+#pragma unroll
+    for (int t = 0; t < stride; ++t)
+      if (v[t] < v[t + stride]) {
+        v[t] = v[t + stride];
+        id[t] = id[t + stride];
+      }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < WIDTH; j += 4) {   // second pass over the row (L1-resident)
+    const f32x4 t = ldg4(row + j);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum += expf(t[q] - v[0]);
+  }
+  *idx_out = id[0];
+  *val_out = 1.f / sum;
+}
+
+// GATE_W > 0: the kernel first forms gate_idx / gate_value from router logits [S][GATE_W] (one lane per
+// token; padded frames t >= len[b] get idx -1 / value 0), i.e. SoftmaxTopK + ScatterMapping in one launch.
+template <int GATE_W>
+__global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in, int S, int E, int nbits,
                                                          int32_t* __restrict__ mapping, int32_t* __restrict__ acc_hist,
-                                                         int32_t* __restrict__ pos) {
+                                                         int32_t* __restrict__ pos, const float* __restrict__ logits,
+                                                         const int32_t* __restrict__ row_len, int rows_per_batch,
+                                                         int32_t* gate_out, float* __restrict__ gate_value) {
   __shared__ int hist[kIdxMaxE];
   __shared__ int running[kIdxMaxE];
   __shared__ int wcnt[kIdxMaxWaves][kIdxMaxE];
@@ -41,8 +83,20 @@ __global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int32_t* gate = gate_in;
 
   for (int e = tid; e < E; e += nthreads) hist[e] = 0;
+  if (GATE_W > 0) {
+    for (int i = tid; i < S; i += nthreads) {
+      int gi = -1;
+      float gv = 0.f;
+      const bool live = row_len == nullptr || (i % rows_per_batch) < row_len[i / rows_per_batch];
+      if (live) gate_top1_lane<(GATE_W > 0 ? GATE_W : 8)>(logits + (size_t)i * GATE_W, &gi, &gv);
+      gate_out[i] = gi;
+      gate_value[i] = gv;
+    }
+    gate = gate_out;   // re-read below by the same workgroup, after the barrier
+  }
   __syncthreads();
 
   // pass 1: histogram (order-independent -> LDS atomics by the wave leaders are fine)
@@ -115,8 +169,31 @@ int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, in
   int nbits = 0;
   while ((1 << nbits) < E) ++nbits;
   int threads = S >= 1024 ? 1024 : (int)align_up(S > 0 ? S : 1, 64);
-  hipLaunchKernelGGL(moe_index_kernel, dim3(1), dim3(threads), 0, stream, gate_idx, S, E, nbits, mapping,
-                     acc_hist, pos);
+  hipLaunchKernelGGL(moe_index_kernel<0>, dim3(1), dim3(threads), 0, stream, gate_idx, S, E, nbits, mapping,
+                     acc_hist, pos, nullptr, nullptr, 0, nullptr, nullptr);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_moe_gate_index(const float* logits, int width, const int32_t* row_len, int rows_per_batch, int S,
+                          int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
+                          hipStream_t stream) {
+  M3_REQUIRE(S > 0, "moe_gate_index: empty batch");
+  M3_REQUIRE(row_len == nullptr || rows_per_batch > 0, "moe_gate_index: rows_per_batch missing");
+  int nbits = 0;
+  while ((1 << nbits) < width) ++nbits;
+  int threads = S >= 1024 ? 1024 : (int)align_up(S, 64);
+#define M3_GI_CASE(W_)                                                                                        \
+  hipLaunchKernelGGL(moe_index_kernel<W_>, dim3(1), dim3(threads), 0, stream, nullptr, S, W_, nbits, mapping, \
+                     acc_hist, pos, logits, row_len, rows_per_batch, gate_idx, gate_value)
+  switch (width) {
+    case 8: M3_GI_CASE(8); break;
+    case 16: M3_GI_CASE(16); break;
+    case 32: M3_GI_CASE(32); break;
+    case 64: M3_GI_CASE(64); break;
+    default: M3_REQUIRE(false, "moe_gate_index: num_expert=%d must be 8/16/32/64", width);
+  }
+#undef M3_GI_CASE
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,7 @@ class LinearDesc(C.Structure):  # m3_linear_desc
                 ("y", C.c_void_p), ("ldy", C.c_int32),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("ln_wsum", C.c_void_p), ("ln_wbeta", C.c_void_p),
                 ("len", C.c_void_p), ("rows_per_batch", C.c_int32), ("mask_in", C.c_int32), ("mask_out", C.c_int32),
                 ("act", C.c_int32), ("alpha", C.c_float),
                 ("resid", C.c_void_p), ("ldr", C.c_int32)]

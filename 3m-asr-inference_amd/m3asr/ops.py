@@ -95,8 +95,10 @@ def softmax_top1(logits, lens=None, rows_per_batch=0):
 
 # ---------------------------------------------------------------------------------------- dense
 def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows_per_batch=0, mask_in=False,
-           mask_out=False, alpha=1.0, resid=None, out=None):
-    """y = resid + alpha * mask_out(act(LN(mask_in(cat[a,a2])) @ w^T + bias)); a (M,K1), w (N,K)."""
+           mask_out=False, alpha=1.0, resid=None, out=None, ln_folded=None):
+    """y = resid + alpha * mask_out(act(LN(mask_in(cat[a,a2])) @ w^T + bias)); a (M,K1), w (N,K).
+    ln = (gamma, beta, eps): affine LayerNorm prologue.  ln_folded = (wsum, wbeta or None, eps): w / bias already
+    contain the LayerNorm affine (plan.fold_layernorm) and the kernel normalises its output."""
     lib = _lib.load()
     M, K1 = a.shape
     N, K = w.shape
@@ -114,6 +116,10 @@ def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows
     d.M, d.N, d.K = M, N, K
     if ln is not None:
         d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    if ln_folded is not None:
+        d.ln_wsum, d.ln_eps = ln_folded[0].data_ptr(), float(ln_folded[2])
+        if ln_folded[1] is not None:
+            d.ln_wbeta = ln_folded[1].data_ptr()
     if lens is not None:
         d.len, d.rows_per_batch = lens.data_ptr(), rows_per_batch
     d.mask_in, d.mask_out = int(mask_in), int(mask_out)

@@ -3,13 +3,15 @@
 
 ``pack_weights`` turns a reference-layout state_dict (the keys of ``Net.state_dict()``, builder.py:131-134)
 into the layouts the HIP engine consumes (all build-time host work, done once):
+  * LayerNorms that feed exactly one Linear (norm_ff_macaron, norm_mha, norm_conv, dense norm_ff, after_norm)
+    are folded into it (`*.ln.weight/bias/wsum`): the GEMM runs on the raw rows and normalises its OUTPUT;
   * q/k/v projections fused into one [3D, D] weight + [3D] bias (one GEMM instead of three Linear layers,
     attention.py:334-343);
   * pointwise Conv1d weights (O, I, 1) viewed as [O, I]; depthwise (C,1,K) -> [K, C] (channel-last rows);
   * subsampling conv1 (C,1,3,3) -> [9, C]; conv2 (O,I,3,3) -> [O,3,3,I] (implicit-GEMM K order);
     the Linear after the convs gets its columns permuted from (c, f) to (f, c) because the engine keeps
     activations channel-last (the reference flattens (B,C,T,F)->(B,T,C*F), subsampling.py:141-142);
-  * router_weights [D+De, E] -> transposed [E, D+De];
+  * router_weights [D+De, E] -> transposed [E, D+De]; expert w_2 [E,D,F] -> slice-major [E,F/64,D,64];
   * eval BatchNorm in the conv module (cnn_module_norm='batch_norm') folded into the depthwise conv;
   * the sinusoidal table ``pe`` (positional_encoding.py:40-48) for max_len positions;
   * in expert-parallel mode only this rank's expert slice [rank*E_loc, (rank+1)*E_loc) is kept
@@ -53,21 +55,46 @@ def _pack_subsampling(sd, p, out):
     out[p + "out.0.bias"] = sd[p + "out.0.bias"]
 
 
+def fold_layernorm(weight, bias, gamma, beta):
+    """Linear(LayerNorm(x)) = ((x - mean) * rstd) @ (W * gamma)^T + (b + W @ beta): the LayerNorm's affine moves
+    into the Linear, so the GEMM prologue only normalises (one fewer dependent load in a latency-bound kernel)."""
+    w64, g64, b64 = weight.double(), gamma.double(), beta.double()
+    wf = (w64 * g64.unsqueeze(0)).float()
+    return {"ln.weight": wf, "ln.bias": (bias.double() + w64 @ b64).float(),
+            # output-side LayerNorm (gemm.hip LN_EPI): y = rstd * (x . W'^T - mean * wsum) + bias'
+            "ln.wsum": wf.double().sum(1).float(),
+            # a frame masked to 0 AFTER the LayerNorm must see the plain bias: bias' - W.beta
+            "ln.wbeta": (w64 @ b64).float()}
+
+
+def _put_folded(out, prefix, folded, keep_wbeta=False):
+    for k, v in folded.items():
+        if k != "ln.wbeta" or keep_wbeta:
+            out[prefix + k] = v
+
+
 def _pack_block(sd, p, out, norm, moe, cfg):
+    folded = ["norm_ff_macaron", "norm_mha", "norm_conv"] + ([] if moe else ["norm_ff"])
     for n in ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final"):
+        if n not in folded:
+            out[p + n + ".weight"] = sd[p + n + ".weight"]
+            out[p + n + ".bias"] = sd[p + n + ".bias"]
+    for n in ("feed_forward_macaron.w_2", "self_attn.linear_out"):
         out[p + n + ".weight"] = sd[p + n + ".weight"]
         out[p + n + ".bias"] = sd[p + n + ".bias"]
-    for n in ("feed_forward_macaron.w_1", "feed_forward_macaron.w_2", "self_attn.linear_out"):
-        out[p + n + ".weight"] = sd[p + n + ".weight"]
-        out[p + n + ".bias"] = sd[p + n + ".bias"]
+    m = p + "feed_forward_macaron.w_1."
+    _put_folded(out, m, fold_layernorm(sd[m + "weight"], sd[m + "bias"],
+                                       sd[p + "norm_ff_macaron.weight"], sd[p + "norm_ff_macaron.bias"]))
     a = p + "self_attn."
-    out[a + "qkv.weight"] = torch.cat([sd[a + "linear_q.weight"], sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0)
-    out[a + "qkv.bias"] = torch.cat([sd[a + "linear_q.bias"], sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0)
+    wqkv = torch.cat([sd[a + "linear_q.weight"], sd[a + "linear_k.weight"], sd[a + "linear_v.weight"]], 0)
+    bqkv = torch.cat([sd[a + "linear_q.bias"], sd[a + "linear_k.bias"], sd[a + "linear_v.bias"]], 0)
+    _put_folded(out, a + "qkv.", fold_layernorm(wqkv, bqkv, sd[p + "norm_mha.weight"], sd[p + "norm_mha.bias"]))
     out[a + "pos_bias_u"] = sd[a + "pos_bias_u"]
     out[a + "pos_bias_v"] = sd[a + "pos_bias_v"]
     c = p + "conv_module."
-    out[c + "pointwise_conv1.weight"] = sd[c + "pointwise_conv1.weight"].squeeze(-1)
-    out[c + "pointwise_conv1.bias"] = sd[c + "pointwise_conv1.bias"]
+    _put_folded(out, c + "pointwise_conv1.",
+                fold_layernorm(sd[c + "pointwise_conv1.weight"].squeeze(-1), sd[c + "pointwise_conv1.bias"],
+                               sd[p + "norm_conv.weight"], sd[p + "norm_conv.bias"]), keep_wbeta=True)
     out[c + "pointwise_conv2.weight"] = sd[c + "pointwise_conv2.weight"].squeeze(-1)
     out[c + "pointwise_conv2.bias"] = sd[c + "pointwise_conv2.bias"]
     dw = sd[c + "depthwise_conv.weight"].squeeze(1)      # (C, K)
@@ -83,9 +110,10 @@ def _pack_block(sd, p, out, norm, moe, cfg):
     out[c + "depthwise_conv.bias"] = db
     f = p + "feed_forward."
     if not moe:
-        for n in ("w_1", "w_2"):
-            out[f + n + ".weight"] = sd[f + n + ".weight"]
-            out[f + n + ".bias"] = sd[f + n + ".bias"]
+        _put_folded(out, f + "w_1.", fold_layernorm(sd[f + "w_1.weight"], sd[f + "w_1.bias"],
+                                                    sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"]))
+        out[f + "w_2.weight"] = sd[f + "w_2.weight"]
+        out[f + "w_2.bias"] = sd[f + "w_2.bias"]
     else:
         out[f + "router_weights_t"] = sd[f + "router_weights"].t().contiguous()
         if (f + "router_bias") in sd:
@@ -96,7 +124,13 @@ def _pack_block(sd, p, out, norm, moe, cfg):
             if cfg.ep_world_size > 1 and t.shape[0] == cfg.num_experts * cfg.ep_world_size:
                 t = t[lo: lo + cfg.num_experts]
             assert t.shape[0] == cfg.num_experts, "%s: %d experts, config says %d" % (f + n, t.shape[0], cfg.num_experts)
-            out[f + n] = t
+            if n == "experts.w_2.weight":
+                # [E, D, F] -> slice-major [E, F/64, D, 64]: the 128 KB a workgroup of the grouped expert FFN
+                # streams in its second GEMM become one contiguous run
+                E_, D_, F_ = t.shape
+                out[f + "experts.w_2.weight_sliced"] = t.view(E_, D_, F_ // 64, 64).permute(0, 2, 1, 3).contiguous()
+            else:
+                out[f + n] = t
 
 
 def pack_weights(state_dict, cfg: EncoderConfig):
@@ -109,12 +143,10 @@ def pack_weights(state_dict, cfg: EncoderConfig):
     for i in range(cfg.embed_blocks):
         _pack_block(sd, "embed.blocks.%d." % i, out, cfg.embed_cnn_module_norm, False, cfg)
     _pack_subsampling(sd, "subsampling.", out)
-    out["after_norm.weight"] = sd["after_norm.weight"]
-    out["after_norm.bias"] = sd["after_norm.bias"]
     for i in range(cfg.num_blocks):
         _pack_block(sd, "blocks.%d." % i, out, cfg.cnn_module_norm, True, cfg)
-    out["out_linear.weight"] = sd["out_linear.weight"]
-    out["out_linear.bias"] = sd["out_linear.bias"]
+    _put_folded(out, "out_linear.", fold_layernorm(sd["out_linear.weight"], sd["out_linear.bias"],
+                                                   sd["after_norm.weight"], sd["after_norm.bias"]))
     out["pe"] = positional_table(cfg.max_len, cfg.attention_dim)
     # every block's linear_pos weight stacked: p for all blocks = one GEMM per forward (attention.py:345)
     out["pos_all.weight"] = torch.cat(

@@ -132,6 +132,9 @@ typedef struct m3_linear_desc {
   float* y; int32_t ldy;
   int32_t M, N, K;
   const float* ln_gamma; const float* ln_beta; float ln_eps;
+  /* folded LayerNorm (affine pre-multiplied into w / bias by the plan packer): the kernel normalises its
+   * OUTPUT, y = rstd*(a.w^T - mean*ln_wsum) + bias; ln_wbeta = w.beta, needed only together with mask_in */
+  const float* ln_wsum; const float* ln_wbeta;
   const int32_t* len; int32_t rows_per_batch; int32_t mask_in; int32_t mask_out;
   int32_t act; float alpha;
   const float* resid; int32_t ldr;

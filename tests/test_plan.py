@@ -12,8 +12,15 @@ def test_pack_layouts_and_plan_roundtrip(tmp_path):
     w = make_weights(cfg, seed=1)
     p = pack_weights(w, cfg)
     D, F2 = cfg.attention_dim, cfg.sub_freq
-    assert p["blocks.0.self_attn.qkv.weight"].shape == (3 * D, D)
-    assert torch.equal(p["blocks.0.self_attn.qkv.weight"][D:2 * D], w["blocks.0.self_attn.linear_k.weight"])
+    assert p["blocks.0.self_attn.qkv.ln.weight"].shape == (3 * D, D)
+    # LayerNorm affine folded into the projection: Linear(LN(x)) == Linear'(normalise(x))
+    x = torch.randn(5, D, generator=torch.Generator().manual_seed(0))
+    xn = torch.nn.functional.layer_norm(x, (D,), None, None, 1e-12)
+    want = torch.nn.functional.linear(torch.nn.functional.layer_norm(
+        x, (D,), w["blocks.0.norm_mha.weight"], w["blocks.0.norm_mha.bias"], 1e-12),
+        w["blocks.0.self_attn.linear_k.weight"], w["blocks.0.self_attn.linear_k.bias"])
+    got = torch.nn.functional.linear(xn, p["blocks.0.self_attn.qkv.ln.weight"][D:2 * D], p["blocks.0.self_attn.qkv.ln.bias"][D:2 * D])
+    assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
     assert p["subsampling.conv.2.weight_ohwi"].shape == (D, 3, 3, D)
     assert torch.equal(p["subsampling.conv.2.weight_ohwi"][3, 1, 2, 5], w["subsampling.conv.2.weight"][3, 5, 1, 2])
     wl, wr = p["subsampling.out.0.weight"], w["subsampling.out.0.weight"]
@@ -34,6 +41,8 @@ def test_pack_expert_parallel_slice():
     full = make_weights(EncoderConfig.tiny(num_experts=4), seed=1)
     p = pack_weights(full, cfg)     # load_state_dict_comm semantics: keep experts [rank*E_loc, (rank+1)*E_loc)
     assert torch.equal(p["blocks.0.feed_forward.experts.w_1.weight"], full["blocks.0.feed_forward.experts.w_1.weight"][2:4])
+    w2 = full["blocks.0.feed_forward.experts.w_2.weight"][2:4]
+    assert torch.equal(p["blocks.0.feed_forward.experts.w_2.weight_sliced"][1, 0, 5, 7], w2[1, 5, 7])
     assert p["blocks.0.feed_forward.router_weights_t"].shape[0] == 4     # the router still scores all experts
 
 
