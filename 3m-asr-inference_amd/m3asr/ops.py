@@ -250,14 +250,15 @@ def binary(a, b, op):
 
 
 def permute_copy(x, perm):
-    """Materialised permutation (TensorRT shuffle's transpose)."""
+    """Materialised permutation (TensorRT shuffle's transpose); x may be any strided view."""
     lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32
     nd = x.dim()
     out_shape = [x.shape[p] for p in perm]
     in_strides = [x.stride(p) for p in perm]
     y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
     arr = C.c_int64 * nd
-    check(lib.m3_permute(_f32(x), _p(y), arr(*out_shape), arr(*in_strides), nd, _stream()), "m3_permute")
+    check(lib.m3_permute(C.c_void_p(x.data_ptr()), _p(y), arr(*out_shape), arr(*in_strides), nd, _stream()), "m3_permute")
     return y
 
 
@@ -286,7 +287,12 @@ def batched_matmul(a, b, transpose_b=False):
     lead = [max(x, y) for x, y in zip(a.shape[:-2], b.shape[:-2])]
     batch = int(math.prod(lead)) if lead else 1
     na, nb = int(math.prod(a.shape[:-2])), int(math.prod(b.shape[:-2]))
-    assert na in (1, batch) and nb in (1, batch), "only full or fully-broadcast batch dims supported"
+    if na not in (1, batch):      # partial broadcast (e.g. (1,h,..) against (B,h,..)): materialise with the copy kernel
+        a = permute_copy(a.expand(tuple(lead) + tuple(a.shape[-2:])), tuple(range(a.dim())))
+        na = batch
+    if nb not in (1, batch):
+        b = permute_copy(b.expand(tuple(lead) + tuple(b.shape[-2:])), tuple(range(b.dim())))
+        nb = batch
     c = torch.empty(tuple(lead) + (M, N), dtype=torch.float32, device=a.device)
     sa = 0 if na == 1 and batch > 1 else M * K
     sb = 0 if nb == 1 and batch > 1 else b.shape[-2] * b.shape[-1]

@@ -1,0 +1,143 @@
+"""init_trt_plugin / HelperConfig / BuilderHelper with the reference's names and call shapes
+(TRTAPI++/python/trt_helper/builder_helper.py:24-167), on libm3asr_hip.so.
+
+Build semantics.  TensorRT's builder times tactics on dummy tensors of the profile's *opt* shape; ours does the
+analogous thing eagerly: ``addInput`` hands the model code a device tensor of the opt shape, the model's
+``forward(network_helper, ...)`` runs op-by-op through the C ABI, and ``build_engine`` packs the model's weights into a
+plan (m3asr/plan.py), instantiates the fused native engine and checks it against the op-by-op result before writing
+the plan file.  The plan is config + packed weights (the TensorRT plan also embeds weights, builder_helper.py:155-163).
+"""
+import numpy as np
+import torch
+
+from m3asr import _lib
+from m3asr.engine import Engine
+from m3asr.plan import pack_weights, save_plan
+from . import trt
+from .network_helper import NetworkHelper
+
+
+def init_trt_plugin(severity=None, lib_name=None, logger=None):
+    """Load the operator library (reference: ctypes.CDLL(libtrtplugin++.so) + init_libnvinfer_plugins,
+    builder_helper.py:24-45).  lib_name is accepted for drop-in compatibility; the library is libm3asr_hip.so."""
+    if severity is None:
+        severity = trt.Logger.INFO
+    if logger is None:
+        logger = trt.Logger(severity)
+    lib = _lib.load()          # raises if the library has not been built: no silent fallback
+    logger.log(trt.Logger.INFO, "[TrtHelper LOG] m3asr plugin init done! abi=%d, %d plugins registered" % (
+        lib.m3_abi_version(), lib.m3_registry_count()))
+    return logger
+
+
+class HelperConfig:
+    def __init__(self):
+        self.use_fp16 = False
+        self.use_int8 = False
+        self.plugin_data_type = 0        # 0: float, 1: half, 2: int8
+        self.dynamic_shape = True
+        self.max_workspace_size = 3      # GiB
+
+    def log(self):
+        print("=========TrtHelperConfig===========")
+        for k in ("use_fp16", "use_int8", "plugin_data_type", "dynamic_shape", "max_workspace_size"):
+            print("%s: %s" % (k, getattr(self, k)))
+        print("=========TrtHelperConfig===========")
+
+
+class BuiltEngine:
+    """What build_engine returns (the reference returns trt.ICudaEngine and prints its bindings, builder.py:95-98)."""
+
+    def __init__(self, engine, names, shapes):
+        self.engine, self._names, self._shapes = engine, names, shapes
+        self.num_bindings = len(names)
+
+    def get_binding_name(self, i):
+        return self._names[i]
+
+    def binding_is_input(self, i):
+        return i < self.num_bindings - 1
+
+    def get_binding_shape(self, i):
+        return self._shapes[i]
+
+
+class BuilderHelper:
+    def __init__(self, config, logger=None, calibrator=None, device="cuda:0"):
+        self.config = config
+        self.logger = logger if logger is not None else trt.Logger(trt.Logger.INFO)
+        self.config.log()
+        if config.use_fp16 or config.use_int8 or config.plugin_data_type != 0:
+            # the reference wires these flags but never finished them (builder.py:39-49; fmoe asserts on HALF)
+            raise RuntimeError("only fp32 (plugin_data_type 0) is implemented in this round")
+        self.device = torch.device(device)
+        self.profiles = {}
+        self.model, self.model_cfg = None, None
+        self.network_helper = NetworkHelper(None, None, config, self.logger, device=device)
+        self.network_helper._builder = self
+        self.network = self.network_helper.network
+        self._declared = []
+
+    def get_network_helper(self):
+        return self.network_helper
+
+    def add_profile(self, name, min_shape, opt_shape, max_shape):
+        self.profiles[name] = (tuple(min_shape), tuple(opt_shape), tuple(max_shape))
+        self._materialise()
+
+    def note_model(self, state_dict, cfg):
+        """Called by the model's encoder emission: lets build_engine pack the weights it saw."""
+        self.model, self.model_cfg = state_dict, cfg
+
+    # dummy opt-shape inputs for the eager emission (TensorRT profiles its tactics on the opt shape too)
+    def declare_input(self, name, dtype, shape):
+        self._declared.append((name, dtype, tuple(shape)))
+        self._materialise()
+
+    def _materialise(self):
+        for name, dtype, shape in self._declared:
+            if name in self.network_helper._bound or name not in self.profiles:
+                continue
+            opt = self.profiles[name][1]
+            if dtype in (trt.int32, torch.int32):
+                t = None      # lengths are filled from the feature profile below
+            else:
+                g = torch.Generator().manual_seed(1234)
+                t = torch.rand(opt, generator=g, dtype=torch.float32)
+            if t is not None:
+                self.network_helper.bind_input(name, t)
+        if "feat" in self.network_helper._bound and "feat_len" in self.profiles and "feat_len" not in self.network_helper._bound:
+            f = self.network_helper._bound["feat"]
+            B, T = f.shape[0], f.shape[1]
+            lens = torch.tensor([[max(7, T - 37 * i) for i in range(B)]], dtype=torch.int32)
+            self.network_helper.bind_input("feat_len", lens)
+
+    def build_engine(self, engine_name=None):
+        if self.model is None:
+            raise RuntimeError("build_engine: no encoder was emitted through this network_helper")
+        nh = self.network_helper
+        if not nh.outputs:
+            raise RuntimeError("build_engine: no output marked")
+        packed = pack_weights(self.model, self.model_cfg)
+        eng = Engine(self.model_cfg, packed, device=str(self.device))
+        feat, feat_len = nh.inputs["feat"], nh.inputs["feat_len"]
+        fused = eng(feat, feat_len)
+        ref = nh.outputs[-1]
+        extra = getattr(self, "output_bias", None)
+        if extra is not None:
+            fused = fused + extra.to(fused.device)
+        lens = eng.buffer("lens", torch.int32).cpu()
+        valid = (torch.arange(fused.shape[1]).view(1, -1) < lens.view(-1, 1)).to(fused.device)
+        err = float(((fused - ref).abs() * valid.unsqueeze(-1)).max())
+        scale = float(ref.abs().max())
+        self.logger.log(trt.Logger.INFO, "[Builder] fused engine vs op-by-op emission: max abs diff %.3e (max |logit| %.3e)" % (err, scale))
+        if not err <= 1e-3 * max(scale, 1.0):
+            raise RuntimeError("build_engine: fused engine disagrees with the emitted network (%.3e)" % err)
+        if engine_name is not None:
+            save_plan(engine_name, self.model_cfg, packed,
+                      extra={"profiles": {k: [list(s) for s in v] for k, v in self.profiles.items()},
+                             "output_bias": extra.flatten().tolist() if extra is not None else None})
+            self.logger.log(trt.Logger.INFO, "[Builder] plan written to " + engine_name)
+        names = list(nh.inputs) + ["output"]
+        shapes = [tuple(-1 for _ in nh.inputs[n].shape) for n in nh.inputs] + [(-1, -1, self.model_cfg.output_dim)]
+        return BuiltEngine(eng, names, shapes)

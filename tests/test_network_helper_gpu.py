@@ -1,0 +1,79 @@
+"""GPU: the drop-in operator surface.  The model description emits the encoder op by op through
+network_helper.add* and the *PluginDynamic operators (reference layouts, generic m3_plugin_* C ABI); the result must
+equal the golden logits and the fused native engine.  Also the builder.py -> plan -> infer.py round trip."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+import trt_helper
+from trt_helper import trt
+from m3asr.weights import make_weights
+from model.conformer_fmoe_localComm_catEmbed_domain_acc_hier import Net
+
+
+def _reference_conf(cfg):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_synthetic_checkpoint import reference_yaml
+    return reference_yaml(cfg)["model_conf"]["encoder_conf"]
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_op_by_op_emission_matches_golden(golden, name):
+    cfg, z = golden(name)
+    net = Net(cfg.input_dim, cfg.output_dim, **_reference_conf(cfg))
+    assert net.cfg == cfg
+    net.load_state_dict(make_weights(cfg, seed=int(z["weight_seed"])))
+    nh = trt_helper.NetworkHelper(config=trt_helper.HelperConfig())
+    nh.bind_input("feat", torch.from_numpy(z["feat"]))
+    nh.bind_input("feat_len", torch.from_numpy(z["feat_len"]).view(1, -1))
+    feat = nh.addInput("feat", trt.float32, (-1, -1, cfg.input_dim))
+    feat_len = nh.addInput("feat_len", trt.int32, (1, -1))
+    out = net(nh, feat, feat_len)
+    nh.markOutput(out)
+    got, want = out.cpu(), torch.from_numpy(z["logits"])
+    valid = torch.arange(got.shape[1]).view(1, -1) < torch.from_numpy(z["out_len"]).view(-1, 1)
+    err = (got - want).abs()[valid]
+    assert bool((err <= 2e-4 + 1e-3 * want.abs()[valid]).all()), float(err.max())
+
+
+def test_plugin_errors_follow_the_reference():
+    nh = trt_helper.NetworkHelper(config=trt_helper.HelperConfig())
+    assert nh.plugin_registry.get_plugin_creator("NoSuchPluginDynamic", "1", "") is None
+    creator = nh.plugin_registry.get_plugin_creator("FMoEExpertPluginDynamic", "1", "")
+    bad = trt.PluginFieldCollection([trt.PluginField("data_type", np.array([0], np.int32), trt.PluginFieldType.INT32)])
+    assert creator.create_plugin("plugin", bad) is None            # missing num_expert/idim/hidden_units -> null plugin
+    with pytest.raises(RuntimeError):
+        nh.addGelu(torch.zeros(1, 1, 1, device="cuda"))             # not on the hot path: "not support", as in the reference
+    x = torch.zeros(2, 3, 8, device="cuda")
+    with pytest.raises(RuntimeError):
+        nh.addScale(x.view(6, 8), 2.0)                              # rank < 3 (tensor_network_helper.py:445-447)
+
+
+def test_builder_and_infer_cli_round_trip(tmp_path):
+    d = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "3m-asr-inference_amd"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_checkpoint.py"), "--out-dir", d,
+                           "--tiny", "--seed", "3"], env=env)
+    plan = os.path.join(d, "enc.plan")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "builder.py"), "-c", os.path.join(d, "config.yaml"),
+                                   "-m", os.path.join(d, "model.pt"), "-o", plan, "--opt-shape", "2x64"], env=env, text=True)
+    assert "fused engine vs op-by-op emission" in out and os.path.exists(plan)
+    feat = np.random.default_rng(0).random((1, 206, 40), dtype=np.float32)
+    np.save(os.path.join(d, "feat.npy"), feat)
+    # expected output from the CPU oracle (the checker), written as the reference's -o compare file
+    from m3asr.config import EncoderConfig
+    from oracle.encoder_ref import encoder_forward
+    cfg = EncoderConfig.tiny()
+    want = encoder_forward(make_weights(cfg, seed=3), cfg, torch.from_numpy(feat), torch.tensor([206])).numpy()
+    np.save(os.path.join(d, "want.npy"), want)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "infer.py"), "-p", plan, "-i", os.path.join(d, "feat.npy"),
+                                   "-o", os.path.join(d, "want.npy")], env=env, text=True)
+    assert "time=" in out and "torch.allclose result:True" in out

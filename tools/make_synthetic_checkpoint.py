@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Write a synthetic checkpoint + yaml config in the reference's formats (the real ones are not shipped,
+README.md:6,13): ``python tools/make_synthetic_checkpoint.py --out-dir /tmp/m3 [--tiny] [--layers 18]``."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "3m-asr-inference_amd"))
+import torch
+import yaml
+
+from m3asr.config import EncoderConfig
+from m3asr.weights import make_weights
+
+
+def reference_yaml(cfg):
+    return {"nnet_proto": "conformer_aed_fmoe_localComm_catEmbed_domain_acc_hier", "output_dim": cfg.output_dim,
+            "model_conf": {"encoder_conf": {
+                "attention_heads": cfg.attention_heads, "attention_dim": cfg.attention_dim, "num_blocks": cfg.num_blocks,
+                "cnn_module_kernel": cfg.cnn_module_kernel, "cnn_module_norm": cfg.cnn_module_norm,
+                "embed_conf": {"attention_heads": cfg.embed_heads, "attention_dim": cfg.embed_dim,
+                               "linear_units": cfg.embed_linear_units, "num_blocks": cfg.embed_blocks,
+                               "cnn_module_norm": cfg.embed_cnn_module_norm},
+                "moe_conf": {"num_experts": cfg.num_experts, "hidden_units": cfg.hidden_units}}}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out-dir", required=True)
+    ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--layers", type=int, default=18)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    cfg = EncoderConfig.tiny() if a.tiny else EncoderConfig(num_blocks=a.layers)
+    os.makedirs(a.out_dir, exist_ok=True)
+    sd = {"encoder." + k: v for k, v in make_weights(cfg, seed=a.seed).items()}
+    torch.save(sd, os.path.join(a.out_dir, "model.pt"))
+    with open(os.path.join(a.out_dir, "config.yaml"), "w") as f:
+        yaml.safe_dump(reference_yaml(cfg), f)
+    print("wrote", a.out_dir)
+
+
+if __name__ == "__main__":
+    main()
