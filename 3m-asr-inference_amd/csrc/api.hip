@@ -87,6 +87,13 @@ int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, 
   return moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, S, num_expert, idim, hidden_units, gate_value, resid, alpha,
                         ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes, (hipStream_t)stream);
 }
+int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid, float alpha,
+                   const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int idim,
+                   m3_stream stream) {
+  M3_REQUIRE(rows && mapping && out, "moe_combine: null pointer");
+  return launch_moe_combine(rows, 1, mapping, nullptr, gate_value, nullptr, resid, alpha, ln_gamma, ln_beta, ln_eps, out,
+                            S, idim, (hipStream_t)stream);
+}
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
                     int32_t* idx, float* value, m3_stream stream) {
   return launch_softmax_top1(logits, ld, len, rows_per_batch, S, width, idx, value, (hipStream_t)stream);

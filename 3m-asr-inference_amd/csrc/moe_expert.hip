@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
   const int s = blockIdx.x * 4 + wave;
   if (s >= S) return;
   const int m = mapping[s];
-  const int g = gate_idx[s];
+  const int g = gate_idx ? gate_idx[s] : 0;
   const float gate = (m >= 0) ? (gate_value ? gate_value[s] : 1.f) : 0.f;
   f32x4 v[NV];
   float sum = 0.f;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
     if (c < D) {
       f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
       if (m >= 0) {
-        y = ldg4(b2 + (size_t)g * D + c);
+        if (b2) y = ldg4(b2 + (size_t)g * D + c);
         for (int k0 = 0; k0 < n_slices; k0 += 8) {   // 8 slab rows in flight, summed in slice order
           f32x4 t[8];
 #pragma unroll

@@ -82,6 +82,7 @@ SIGNATURES = {
     "m3_moe_expert_workspace_size": (_sz, [_i, _i, _i, _i]),
     "m3_moe_expert_ffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                _vp, _sz, _vp]),
+    "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "m3_linear": (_i, [_P(LinearDesc), _vp]),
     "m3_layer_norm": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),

@@ -81,6 +81,18 @@ def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alp
     return y
 
 
+def moe_combine(rows, mapping, gate_value=None, resid=None, alpha=1.0, ln=None, out=None):
+    """out[s] = LN(resid[s] + alpha * gate[s] * rows[mapping[s]]); rows are in scattered (expert-sorted) order."""
+    lib = _lib.load()
+    S, D = mapping.numel(), rows.shape[-1]
+    y = out if out is not None else torch.empty(S, D, dtype=torch.float32, device=rows.device)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    check(lib.m3_moe_combine(_f32(rows), _i32(mapping), _f32(gate_value.reshape(-1) if gate_value is not None else None),
+                             _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), S, D, _stream()),
+          "m3_moe_combine")
+    return y
+
+
 def softmax_top1(logits, lens=None, rows_per_batch=0):
     lib = _lib.load()
     E = logits.shape[-1]

@@ -112,6 +112,13 @@ int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, 
                       const float* gate_value, const float* resid, float alpha, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, float* y, void* workspace, size_t workspace_bytes,
                       m3_stream stream);
+/* The tail of the MoE layer on rows that are already in scattered (expert-sorted) order, e.g. rows that came back
+ * from the expert-parallel all-to-all:  out[s] = LayerNorm( resid[s] + alpha * gate_value[s] * rows[mapping[s]] )
+ * (rows with mapping < 0 contribute 0; gate_value / resid / ln_* may be NULL).  = local_gather
+ * (fmoe/functions.py:194) + addProd + addScale + addAdd + norm_final (fmoe_transformer.py:145-166). */
+int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid,
+                   float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S,
+                   int idim, m3_stream stream);
 /* Replaces ComputeSoftmaxAndTop1 (softmax_topk_kernel.cu:88-120): logits [S][ld] -> idx[S], value[S];
  * frames t >= len[b] (t = s % rows_per_batch, b = s / rows_per_batch) get idx -1 / value 0; len may be NULL. */
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
