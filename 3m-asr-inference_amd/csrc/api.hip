@@ -76,6 +76,7 @@ int m3_moe_local_scatter(const void* x, const int32_t* mapping, int S, int row_b
 int m3_moe_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, m3_stream stream) {
   return launch_local_gather(buf, mapping, S, row_bytes, out, (hipStream_t)stream);
 }
+int m3_moe_expert_slice(void) { return kExpertSlice; }
 size_t m3_moe_expert_workspace_size(int S, int num_expert, int idim, int hidden_units) {
   if (S <= 0 || hidden_units % kExpertSlice) return 0;
   return carve_moe_workspace(nullptr, S, num_expert, idim, hidden_units).bytes;

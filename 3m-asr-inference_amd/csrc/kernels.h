@@ -47,7 +47,7 @@ int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_b
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 
 // ---- grouped expert FFN (moe_expert.hip) ----
-constexpr int kExpertSlice = 64;  // hidden units per workgroup
+constexpr int kExpertSlice = 64;  // hidden units per workgroup (16 per wave); m3asr/plan.py EXPERT_SLICE must match
 size_t expert_ffn_slab_bytes(int S, int D, int F);
 int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,

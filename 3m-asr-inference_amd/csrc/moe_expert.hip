@@ -17,13 +17,15 @@
 //      residual and optionally the block's final LayerNorm, and un-permutes rows (local_gather).
 // Arithmetic: v_mfma_f32_16x16x4_f32 (exact fp32).  At B=1x206 (S=50, ~2 rows/expert) the launch is
 // pure weight streaming: 4.2 MB per touched expert, E*F/64 = 512 workgroups of 256 KB each.
+// Measured dead ends: a persistent work-queue form (atomic item counter) was 30 % slower,
+// 32-wide slices and 3-4 deep load rings did not move the time: the kernel sits at the ~24 GB/s a CU can pull.
 #include "common.h"
 #include "kernels.h"
 
 namespace m3 {
 
 template <int MT>
-__global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kernel(const float* __restrict__ x, int ldx,
                                                              const int32_t* __restrict__ pos,
                                                              const int32_t* __restrict__ acc_hist, int S, int D,
                                                              int F, const float* __restrict__ w1,
@@ -39,6 +41,11 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
   const int col = lane & 15, kq = lane >> 4;
   const int xs_ld = D + 8;                   // +8 floats: conflict-free ds_read_b128 of A fragments
   constexpr int hs_ld = kExpertSlice + 8;
+  constexpr int NWV = kExpertSlice / 16;     // waves per workgroup, 16 hidden units each
+  constexpr int KS2 = kExpertSlice / 16;     // 16-deep k-steps of phase 2
+  constexpr int SPG = 8 / KS2;               // phase-2 output tiles per 8-float4 load group
+  constexpr int NB = 2;   // load groups in the register ring
+  static_assert(kExpertSlice == 16 || kExpertSlice == 32 || kExpertSlice == 64, "slice must be 16/32/64");
   float* xs = lds;                           // [16*MT][D+8]
   float* hs = lds + 16 * MT * xs_ld;         // [16*MT][64+8]
   const int f0 = slice * kExpertSlice;
@@ -54,15 +61,15 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
   // One stream of weight loads per wave: g1 groups of 8 W1 k-steps, then g2 groups of 2 W2 tiles
   // (8 float4 each), double-buffered so 8-16 float4 per lane stay in flight across the phase change.
   const int g1 = (ksteps1 + 7) >> 3;
-  const int g2 = (((nsub + 3) >> 2) + 1) >> 1;   // same for every wave (the barrier sits inside the loop)
+  const int g2 = ((nsub + NWV - 1) / NWV + SPG - 1) / SPG;   // same for every wave (the barrier sits inside the loop)
   const int total = g1 + g2;
 
   for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
     const int nrows = min(16 * MT, row_hi - r0);
     float* slab_base = slab + ((size_t)slice * S + r0) * D;
 
-    f32x4 wb[2][8];
-    auto load_group = [&](int g, int buf) {      // buf is a literal at every call site
+    f32x4 wb[NB][8];
+    auto load_group = [&](int g, int buf) {      // buf is a compile-time constant at every call site
       if (g < g1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -71,11 +78,11 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int sub = min(wave + 4 * (2 * (g - g1) + j), nsub - 1);
+        for (int j = 0; j < SPG; ++j) {
+          const int sub = min(wave + NWV * (SPG * (g - g1) + j), nsub - 1);
           const float* p = w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 4 * kq;
 #pragma unroll
-          for (int st = 0; st < 4; ++st) wb[buf][4 * j + st] = ldg4(p + 16 * st);
+          for (int st = 0; st < KS2; ++st) wb[buf][KS2 * j + st] = ldg4(p + 16 * st);
         }
       }
     };
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
 
     // ---- gather token rows into LDS (fused local_scatter) ----
     __syncthreads();    // previous row tile is done with xs / hs
-    for (int i = wave; i < 16 * MT; i += 4) {
+    for (int i = wave; i < 16 * MT; i += NWV) {
       float* dst = xs + i * xs_ld;
       if (i < nrows) {
         const float* src = x + (size_t)pos[r0 + i] * ldx;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
     f32x4 acc1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 hfrag[MT][4];
+    f32x4 hfrag[MT][KS2];
 
     // phase change: H = SiLU(acc1 + b1) -> LDS -> A fragments of phase 2
     auto transition = [&]() {
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < KS2; ++st)
           hfrag[mt][st] = *reinterpret_cast<const f32x4*>(hs + (16 * mt + col) * hs_ld + 16 * st + 4 * kq);
     };
     auto compute = [&](int g, int buf) {
@@ -129,16 +136,16 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
         }
       } else {        // phase 2: Ypart[:, 16*sub .. +16) = H[:, slice] . W2[e][:, slice]^T
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int sub = wave + 4 * (2 * (g - g1) + j);
+        for (int j = 0; j < SPG; ++j) {
+          const int sub = wave + NWV * (SPG * (g - g1) + j);
           if (sub < nsub) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int st = 0; st < 4; ++st)
+              for (int st = 0; st < KS2; ++st)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc2 = mfma16(hfrag[mt][st][jj], wb[buf][4 * j + st][jj], acc2);
+                for (int jj = 0; jj < 4; ++jj) acc2 = mfma16(hfrag[mt][st][jj], wb[buf][KS2 * j + st][jj], acc2);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int i = 16 * mt + 4 * kq + r;
@@ -150,14 +157,19 @@ __global__ __launch_bounds__(256) void expert_ffn_f32_kernel(const float* __rest
       }
     };
 
-    for (int g = 0; g < total; g += 2) {
-      if (g + 1 < total) load_group(g + 1, 1);
-      if (g == g1) transition();
-      compute(g, 0);
-      if (g + 1 < total) {
-        if (g + 2 < total) load_group(g + 2, 0);
-        if (g + 1 == g1) transition();
-        compute(g + 1, 1);
+    // ring of NB groups: while group g is consumed, groups g+1 .. g+NB-1 are in flight (8*(NB-1) float4 per lane)
+#pragma unroll
+    for (int b = 1; b < NB - 1; ++b)
+      if (b < total) load_group(b, b);
+    for (int g0 = 0; g0 < total; g0 += NB) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int g = g0 + b;
+        if (g < total) {
+          if (g + NB - 1 < total) load_group(g + NB - 1, (b + NB - 1) % NB);
+          if (g == g1) transition();
+          compute(g, b);
+        }
       }
     }
   }
@@ -196,7 +208,7 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
   if (int rc = init_expert_ffn_kernels()) return rc;
 #define M3_EXPERT_CASE(MT_)                                                                             \
-  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(256), lds_bytes, stream, x, ldx, pos,    \
+  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, pos,    \
                      acc_hist, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
 #undef M3_EXPERT_CASE

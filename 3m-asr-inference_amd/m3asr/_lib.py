@@ -79,6 +79,7 @@ SIGNATURES = {
     "m3_moe_scatter_mapping": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "m3_moe_local_scatter": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "m3_moe_local_gather": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "m3_moe_expert_slice": (_i, []),
     "m3_moe_expert_workspace_size": (_sz, [_i, _i, _i, _i]),
     "m3_moe_expert_ffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                _vp, _sz, _vp]),

@@ -33,12 +33,16 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps):
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False):
-        """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors)."""
+        """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors), or the ``weights`` dict of another
+        Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
+        multiple IExecutionContexts per engine)."""
         self.lib = _lib.load()
+        from .plan import EXPERT_SLICE
+        assert self.lib.m3_moe_expert_slice() == EXPERT_SLICE, "plan.EXPERT_SLICE out of sync with libm3asr_hip.so"
         self.cfg = cfg
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.weights = {k: v.to(self.device, non_blocking=False).contiguous() for k, v in packed.items()}
+        self.weights = {k: (v if v.is_cuda else v.to(self.device, non_blocking=False)).contiguous() for k, v in packed.items()}
         names = list(self.weights)
         table = (_lib.WeightEntry * len(names))()
         self._keep = [n.encode() for n in names]
@@ -57,6 +61,10 @@ class Engine:
     @classmethod
     def from_state_dict(cls, cfg, state_dict, **kw):
         return cls(cfg, pack_weights(state_dict, cfg), **kw)
+
+    def clone_context(self, **kw):
+        """Another execution context (own stream, workspace, hipGraph) over the SAME device weights."""
+        return Engine(self.cfg, self.weights, device=str(self.device), **kw)
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None

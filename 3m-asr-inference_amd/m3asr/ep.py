@@ -118,9 +118,9 @@ class ExpertParallelEncoder:
             p = "blocks.%d." % i
             w = engine.weights
             E, D, F = cfg.num_experts, cfg.attention_dim, cfg.hidden_units
-            # the plan keeps w_2 slice-major [E, F/64, D, 64] for the fused engine; the C-ABI op takes the reference
+            # the plan keeps w_2 slice-major [E, F/S, D, S] for the fused engine; the C-ABI op takes the reference
             # layout [E, D, F] -> undo once at set-up
-            w2 = w[p + "feed_forward.experts.w_2.weight_sliced"].view(E, F // 64, D, 64).permute(0, 2, 1, 3).reshape(E, D, F).contiguous()
+            w2 = w[p + "feed_forward.experts.w_2.weight_sliced"].permute(0, 2, 1, 3).reshape(E, D, F).contiguous()
             self.layers.append({"w": {"w1": w[p + "feed_forward.experts.w_1.weight"], "b1": w[p + "feed_forward.experts.w_1.bias"],
                                       "w2": w2, "b2": w[p + "feed_forward.experts.w_2.bias"]},
                                 "ln": (w[p + "norm_final.weight"], w[p + "norm_final.bias"], 1e-12)})

@@ -31,6 +31,7 @@ import torch
 from .config import EncoderConfig
 
 MAGIC = b"M3ASRPL1"
+EXPERT_SLICE = 64    # = m3_moe_expert_slice() of libm3asr_hip.so (checked when an Engine is created)
 
 
 def positional_table(max_len, d):
@@ -125,10 +126,10 @@ def _pack_block(sd, p, out, norm, moe, cfg):
                 t = t[lo: lo + cfg.num_experts]
             assert t.shape[0] == cfg.num_experts, "%s: %d experts, config says %d" % (f + n, t.shape[0], cfg.num_experts)
             if n == "experts.w_2.weight":
-                # [E, D, F] -> slice-major [E, F/64, D, 64]: the 128 KB a workgroup of the grouped expert FFN
+                # [E, D, F] -> slice-major [E, F/S, D, S] (S = EXPERT_SLICE): the bytes a workgroup of the grouped expert FFN
                 # streams in its second GEMM become one contiguous run
                 E_, D_, F_ = t.shape
-                out[f + "experts.w_2.weight_sliced"] = t.view(E_, D_, F_ // 64, 64).permute(0, 2, 1, 3).contiguous()
+                out[f + "experts.w_2.weight_sliced"] = t.view(E_, D_, F_ // EXPERT_SLICE, EXPERT_SLICE).permute(0, 2, 1, 3).contiguous()
             else:
                 out[f + n] = t
 

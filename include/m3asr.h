@@ -101,6 +101,9 @@ int m3_moe_local_scatter(const void* x, const int32_t* mapping, int S, int row_b
  * (fmoe/functions.py:194):  out[s] = buf[mapping[s]] (0 for dropped rows). */
 int m3_moe_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out,
                         m3_stream stream);
+/* Hidden units per work-group of the grouped expert FFN: the engine's expert w_2 is stored slice-major
+ * [E][F/slice][D][slice] (m3asr/plan.py); plugin-path weights keep the reference layout [E][D][F]. */
+int m3_moe_expert_slice(void);
 /* Workspace of m3_moe_expert_ffn / FMoEExpertPluginDynamic (reference layout: fmoe_expert_plugin.cpp:224-239). */
 size_t m3_moe_expert_workspace_size(int S, int num_expert, int idim, int hidden_units);
 /* Replaces compute_fmoe_expert (fmoe_expert_plugin.cpp:36-142): y[s] = SiLU(x[s] W1[g]^T + b1[g]) W2[g]^T + b2[g]

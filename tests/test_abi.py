@@ -82,7 +82,7 @@ def test_plugin_creation_attribute_checks(lib_path):
     t.ndim, t.dtype = 3, 0
     t.shape[0], t.shape[1], t.shape[2] = 1, 50, 512
     ws = lib.m3_plugin_workspace_size(p, ctypes.byref(t), 1, None, 0)
-    assert ws == lib.m3_moe_expert_workspace_size(50, 32, 512, 1024) and ws >= 16 * 50 * 512 * 4
+    assert ws == lib.m3_moe_expert_workspace_size(50, 32, 512, 1024) and ws >= 50 * 512 * 4
     # serialize / deserialize / clone round trip
     nbytes = lib.m3_plugin_serialization_size(p)
     buf = ctypes.create_string_buffer(nbytes)
