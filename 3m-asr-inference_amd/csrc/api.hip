@@ -50,7 +50,7 @@ int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, con
              w.bytes);
   int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
   if (rc) return rc;
-  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
+  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
   if (rc) return rc;
   return launch_moe_combine(w.slab, F / kExpertSlice, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma,
                             ln_beta, ln_eps, y, S, D, stream);

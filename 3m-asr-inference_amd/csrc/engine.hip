@@ -41,7 +41,8 @@ struct BlockW {
   Lin mac1, mac2, qkv, pos, out, pw1, pw2, ff1, ff2;
   const float* pos_u = nullptr; const float* pos_v = nullptr;
   const float* dw_w = nullptr; const float* dw_b = nullptr;
-  Lin router;                       // w: [E_total][D + De]
+  Lin router;                       // w: [E_total][D + De]  (unfused route path)
+  Lin router_x;                     // w: [E][D] x-half with norm_ff folded (+ wsum, bias)  (fused route path)
   const float *ew1 = nullptr, *eb1 = nullptr, *ew2 = nullptr, *eb2 = nullptr;
 };
 
@@ -67,6 +68,7 @@ struct m3_engine {
   const float* pe = nullptr;
   int64_t pe_rows = 0;
   const float* pos_all = nullptr;   // [(embed_blocks + num_blocks) * D][D]: every block's linear_pos weight
+  const float* router_e_all = nullptr;   // [num_blocks * E][De]: embed half of every layer's router (fused route path)
 
   // bound shape
   int B = 0, T = 0, Tp = 0, S = 0;
@@ -146,6 +148,7 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
     const int64_t Etot = (int64_t)c.num_experts * world;
     GET(b->router.w, p + "feed_forward.router_weights_t", Etot * (D + De));
     if (c.router_with_bias) GET(b->router.b, p + "feed_forward.router_bias", Etot);
+    if (c.fuse_route && !load_lin_ln(e, p + "feed_forward.router_x.", Etot, D, false, &b->router_x)) return false;
     const int64_t E = c.num_experts;
     GET(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
     GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
@@ -180,7 +183,7 @@ struct Carver {
 // Buffer plan of one bound shape (identical code computes the size and the addresses).
 struct Plan {
   int32_t* lens;
-  float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl;
+  float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
   void* moe_ws; size_t moe_ws_bytes;
   float* taps;                          // [n_blocks_total][S][D] when debug_taps
@@ -210,6 +213,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.dw = cv.take<float>((size_t)S * D);
   p.xn = cv.take<float>((size_t)S * D);
   p.rl = cv.take<float>((size_t)S * Etot);
+  p.eall = cv.take<float>((size_t)S * Etot * c.num_blocks);
   p.gate_idx = cv.take<int32_t>((size_t)c.num_blocks * S);
   p.gate_val = cv.take<float>((size_t)c.num_blocks * S);
   p.moe_ws_bytes = carve_moe_workspace(nullptr, S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
@@ -327,6 +331,26 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     int32_t* gidx = pl.gate_idx + (size_t)layer * S;
     float* gval = pl.gate_val + (size_t)layer * S;
     const float* ng = w.n_ff.g; const float* nb = w.n_ff.b;
+    void* mws = (char*)pl.moe_ws + (c.debug_taps ? (size_t)layer * pl.moe_ws_bytes : 0);
+    const MoeWorkspace mw = carve_moe_workspace(mws, S, E, D, F);
+    const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
+    const float* fg = w.n_final.g; const float* fb = w.n_final.b;
+    const float* gv = c.keep_expert_output ? nullptr : gval;
+    const bool fused_route = c.fuse_route && world == 1 && S <= 256 && (E == 16 || E == 32 || E == 64);
+    if (fused_route) {
+      // router (x half, norm_ff folded; embed half precomputed for all layers by "router_e_all") + SoftmaxTopK +
+      // ScatterMapping in ONE launch; the expert kernel applies norm_ff itself while it gathers rows
+      const float* wx = w.router_x.w; const float* wsum = w.router_x.wsum; const float* rb = w.router_x.b;
+      const float* eall = pl.eall + (size_t)layer * E;
+      const int ld_e = c.num_blocks * E;
+      add_stage(e, pfx + "moe_route", 1, [=](hipStream_t s) {
+        return launch_moe_route(x, D, D, wx, wsum, rb, eall, ld_e, eps, lens, Tp, S, E, gidx, gval, mw.mapping, mw.acc,
+                                mw.pos, s);
+      });
+      add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+        return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
+      });
+    } else {
     GemmParams r;
     r.mode = GEMM_A_CONCAT2; r.A = pl.emb; r.lda = De; r.K1 = De; r.A2 = x; r.lda2 = D;
     r.W = w.router.w; r.bias = w.router.b; r.Y = rl; r.ldy = Etot; r.M = S; r.N = Etot; r.K = De + D;
@@ -334,11 +358,6 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // out once as xn, the expert FFN's input
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
     add_gemm(e, pfx + "moe_router", r);
-    void* mws = (char*)pl.moe_ws + (c.debug_taps ? (size_t)layer * pl.moe_ws_bytes : 0);
-    const MoeWorkspace mw = carve_moe_workspace(mws, S, E, D, F);
-    const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
-    const float* fg = w.n_final.g; const float* fb = w.n_final.b;
-    const float* gv = c.keep_expert_output ? nullptr : gval;
     // "moe_local.*" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
     if (world == 1 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch
@@ -354,8 +373,9 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       });
     }
     add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
-      return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
+      return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     });
+    }
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(mw.slab, F / kExpertSlice, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
     });
@@ -417,6 +437,8 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
     e->pe_rows = it->second.numel / D;
   }
   if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all)) return fail(nullptr);
+  if (c.fuse_route && !lookup(e, "router_e_all.weight", (int64_t)c.num_blocks * c.num_experts * De, &e->router_e_all))
+    return fail(nullptr);
   e->eblocks.resize(c.embed_blocks);
   for (int i = 0; i < c.embed_blocks; ++i)
     if (!load_block(e, "embed.blocks." + std::to_string(i) + ".", De, c.embed_linear_units, K, c.embed_cnn_layer_norm,
@@ -484,6 +506,14 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     float* x = pl.x; float* emb = pl.emb;
     const float* g = e->e_after.g; const float* b = e->e_after.b;
     add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); });
+  }
+  // embed half of every layer's router product in one GEMM: emb does not change across the main blocks
+  if (c.fuse_route && (c.ep_world_size <= 1) && S <= 256 &&
+      (c.num_experts == 16 || c.num_experts == 32 || c.num_experts == 64)) {
+    GemmParams g;
+    g.A = pl.emb; g.lda = De; g.W = e->router_e_all; g.Y = pl.eall; g.ldy = c.num_blocks * c.num_experts;
+    g.M = S; g.N = c.num_blocks * c.num_experts; g.K = De;
+    add_gemm(e, "router_e_all", g);
   }
   // ---- main MoE encoder (conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) ----
   build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);

@@ -43,6 +43,11 @@ int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, in
 int launch_moe_gate_index(const float* logits, int width, const int32_t* row_len, int rows_per_batch, int S,
                           int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
                           hipStream_t stream);
+// router (x half, folded LayerNorm) + softmax-top1 + index in one single-workgroup launch (S <= 256)
+int launch_moe_route(const float* x, int ldx, int D, const float* wx, const float* wsum, const float* bias,
+                     const float* eall, int ld_e, float ln_eps, const int32_t* row_len, int rows_per_batch, int S, int E,
+                     int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
+                     hipStream_t stream);
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 
@@ -52,7 +57,7 @@ size_t expert_ffn_slab_bytes(int S, int D, int F);
 int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                           int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
-                          hipStream_t stream);
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,

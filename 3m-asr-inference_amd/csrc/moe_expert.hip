@@ -31,7 +31,9 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
                                                              int F, const float* __restrict__ w1,
                                                              const float* __restrict__ b1,
                                                              const float* __restrict__ w2, int w2_row_stride,
-                                                             int w2_slice_stride, float* __restrict__ slab) {
+                                                             int w2_slice_stride, float* __restrict__ slab,
+                                                             const float* __restrict__ ln_gamma,
+                                                             const float* __restrict__ ln_beta, float ln_eps) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int e = blockIdx.y, slice = blockIdx.x;
   const int row_lo = acc_hist[e], row_hi = acc_hist[e + 1];
@@ -94,7 +96,32 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
       float* dst = xs + i * xs_ld;
       if (i < nrows) {
         const float* src = x + (size_t)pos[r0 + i] * ldx;
-        for (int c = lane * 4; c < D; c += 256) stg4(dst + c, ldg4(src + c));
+        if (ln_gamma != nullptr) {
+          // the layer's LayerNorm (norm_ff) applied on the fly: x is the raw residual stream and the normalised
+          // MoE input never exists in memory (two-pass statistics; the row is L1/L2-resident)
+          float s = 0.f;
+          for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = ldg4(src + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+          }
+          const float mean = wave_sum(s) / (float)D;
+          float q = 0.f;
+          for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = ldg4(src + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q += (v[j] - mean) * (v[j] - mean);
+          }
+          const float rstd = rsqrtf(wave_sum(q) / (float)D + ln_eps);
+          for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = ldg4(src + c), g = ldg4(ln_gamma + c), be = ldg4(ln_beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * g[j] + be[j];
+            stg4(dst + c, o);
+          }
+        } else {
+          for (int c = lane * 4; c < D; c += 256) stg4(dst + c, ldg4(src + c));
+        }
       } else {
         for (int c = lane * 4; c < D; c += 256) stg4(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
       }
@@ -194,7 +221,7 @@ size_t expert_ffn_slab_bytes(int S, int D, int F) {
 
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
                           int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
-                          hipStream_t stream) {
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream) {
   M3_REQUIRE(S > 0 && E > 0, "expert_ffn: empty problem S=%d E=%d", S, E);
   M3_REQUIRE((D & 15) == 0 && D <= 2048, "expert_ffn: idim=%d must be a multiple of 16 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
@@ -209,7 +236,7 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   if (int rc = init_expert_ffn_kernels()) return rc;
 #define M3_EXPERT_CASE(MT_)                                                                             \
   hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, pos,    \
-                     acc_hist, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab)
+                     acc_hist, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab, ln_gamma, ln_beta, ln_eps)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
 #undef M3_EXPERT_CASE
   M3_LAUNCH_CHECK();

@@ -68,14 +68,10 @@ __device__ __forceinline__ void gate_top1_lane(const float* __restrict__ row, in
   *val_out = 1.f / sum;
 }
 
-// GATE_W > 0: the kernel first forms gate_idx / gate_value from router logits [S][GATE_W] (one lane per
-// token; padded frames t >= len[b] get idx -1 / value 0), i.e. SoftmaxTopK + ScatterMapping in one launch.
-template <int GATE_W>
-__global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in, int S, int E, int nbits,
-                                                         int32_t* __restrict__ mapping, int32_t* __restrict__ acc_hist,
-                                                         int32_t* __restrict__ pos, const float* __restrict__ logits,
-                                                         const int32_t* __restrict__ row_len, int rows_per_batch,
-                                                         int32_t* gate_out, float* __restrict__ gate_value) {
+// Stable counting sort of the tokens by expert (see the header comment).  `gate` may point to global memory or to
+// LDS (flat addressing); all threads of the (single) workgroup call this.
+__device__ __forceinline__ void moe_index_body(const int32_t* gate, int S, int E, int nbits, int32_t* __restrict__ mapping,
+                                               int32_t* __restrict__ acc_hist, int32_t* __restrict__ pos) {
   __shared__ int hist[kIdxMaxE];
   __shared__ int running[kIdxMaxE];
   __shared__ int wcnt[kIdxMaxWaves][kIdxMaxE];
@@ -83,20 +79,8 @@ __global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int32_t* gate = gate_in;
 
   for (int e = tid; e < E; e += nthreads) hist[e] = 0;
-  if (GATE_W > 0) {
-    for (int i = tid; i < S; i += nthreads) {
-      int gi = -1;
-      float gv = 0.f;
-      const bool live = row_len == nullptr || (i % rows_per_batch) < row_len[i / rows_per_batch];
-      if (live) gate_top1_lane<(GATE_W > 0 ? GATE_W : 8)>(logits + (size_t)i * GATE_W, &gi, &gv);
-      gate_out[i] = gi;
-      gate_value[i] = gv;
-    }
-    gate = gate_out;   // re-read below by the same workgroup, after the barrier
-  }
   __syncthreads();
 
   // pass 1: histogram (order-independent -> LDS atomics by the wave leaders are fine)
@@ -162,6 +146,31 @@ __global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in,
   }
 }
 
+// GATE_W > 0: the kernel first forms gate_idx / gate_value from router logits [S][GATE_W] (one lane per
+// token; padded frames t >= len[b] get idx -1 / value 0), i.e. SoftmaxTopK + ScatterMapping in one launch.
+template <int GATE_W>
+__global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in, int S, int E, int nbits,
+                                                         int32_t* __restrict__ mapping, int32_t* __restrict__ acc_hist,
+                                                         int32_t* __restrict__ pos, const float* __restrict__ logits,
+                                                         const int32_t* __restrict__ row_len, int rows_per_batch,
+                                                         int32_t* gate_out, float* __restrict__ gate_value) {
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int32_t* gate = gate_in;
+  if (GATE_W > 0) {
+    for (int i = tid; i < S; i += nthreads) {
+      int gi = -1;
+      float gv = 0.f;
+      const bool live = row_len == nullptr || (i % rows_per_batch) < row_len[i / rows_per_batch];
+      if (live) gate_top1_lane<(GATE_W > 0 ? GATE_W : 8)>(logits + (size_t)i * GATE_W, &gi, &gv);
+      gate_out[i] = gi;
+      gate_value[i] = gv;
+    }
+    gate = gate_out;   // re-read by the same workgroup after the barrier inside moe_index_body
+    __syncthreads();
+  }
+  moe_index_body(gate, S, E, nbits, mapping, acc_hist, pos);
+}
+
 int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
                      hipStream_t stream) {
   M3_REQUIRE(E >= 1 && E <= kIdxMaxE, "moe_index: num_expert=%d out of range [1,%d]", E, kIdxMaxE);
@@ -194,6 +203,184 @@ int launch_moe_gate_index(const float* logits, int width, const int32_t* row_len
     default: M3_REQUIRE(false, "moe_gate_index: num_expert=%d must be 8/16/32/64", width);
   }
 #undef M3_GI_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// moe_route_kernel: the whole routing decision of one MoE layer in ONE single-workgroup launch
+//   logits = embed_part[s] + LayerNorm(x[s]) . Wx^T (+ bias)      router matmul on cat([embed, x])
+//                                                                   (positionwise_feed_forward.py:169-180,225)
+//   gate_idx, gate_value = softmax-top1(logits)                    SoftmaxTopK plugin (softmax_topk_kernel.cu:26-120)
+//   mapping, acc_histogram, pos                                    ScatterMapping (fmoe_expert_kernel.cu:25-90)
+// for S <= 256 tokens.  The embed half of the router product does not depend on the layer's input and is
+// computed for all layers at once by one GEMM (engine stage "router_e_all"); here only the K = D half is
+// left: each wave = (16-token tile) x (K part), MFMA 16x16x4, LayerNorm applied on the output side with the
+// affine folded into Wx (as gemm.hip LN_EPI), row sums taken from the A fragments.
+template <int E, int NWV>
+__global__ __launch_bounds__(64 * NWV) void moe_route_kernel(const float* __restrict__ x, int ldx, int D,
+                                                         const float* __restrict__ wx, const float* __restrict__ wsum,
+                                                         const float* __restrict__ bias, const float* __restrict__ eall,
+                                                         int ld_e, float ln_eps, const int32_t* __restrict__ row_len,
+                                                         int rows_per_batch, int S, int nbits,
+                                                         int32_t* __restrict__ gate_idx, float* __restrict__ gate_value,
+                                                         int32_t* __restrict__ mapping, int32_t* __restrict__ acc_hist,
+                                                         int32_t* __restrict__ pos) {
+  constexpr int NT = E / 16;
+  __shared__ float part[NWV][16][E + 1];  // [unit][row][expert] partial logits
+  __shared__ float psum[NWV][16][2];      // [unit][row] partial (sum x, sum x^2)
+  __shared__ float s_wsum[E], s_bias[E];
+  __shared__ int s_gate[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int ntile = (S + 15) >> 4;               // <= NWV
+  const int KP = NWV / ntile;                    // K parts per tile (>= 1)
+  const int nsteps = D >> 4;
+  if (tid < E) {
+    s_wsum[tid] = wsum[tid];
+    s_bias[tid] = bias ? bias[tid] : 0.f;
+  }
+  // the embed half of this thread's logits (phase B) is requested now, so its latency hides under phase A
+  constexpr int EPL0 = E / 16;
+  float epre[EPL0];
+  {
+    const int tk = min(tid >> 4, S - 1);
+#pragma unroll
+    for (int j = 0; j < EPL0; ++j) epre[j] = eall ? eall[(size_t)tk * ld_e + (tid & 15) + 16 * j] : 0.f;
+  }
+  // ---- phase A: partial logits of unit (tile, kpart) = this wave ----
+  const int tile = wave / KP, kp = wave - tile * KP;
+  if (tile < ntile) {
+    const int m = min(16 * tile + col, S - 1);
+    const float* arow = x + (size_t)m * ldx + 4 * kq;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+    for (int s0 = kp; s0 < nsteps; s0 += 4 * KP) {   // 4 K-steps per trip, all loads issued before the MFMAs
+      f32x4 a[4], b[4][NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sidx = min(s0 + i * KP, nsteps - 1);
+        a[i] = ldg4(arow + (sidx << 4));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[i][t] = ldg4(wx + (size_t)(16 * t + col) * D + (sidx << 4) + 4 * kq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (s0 + i * KP < nsteps) {
+          s1 += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+          s2 += (a[i][0] * a[i][0] + a[i][1] * a[i][1]) + (a[i][2] * a[i][2] + a[i][3] * a[i][3]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = mfma16(a[i][j], b[i][t][j], acc[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][16 * t + col] = acc[t][r];
+    s1 += __shfl_xor(s1, 16, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (kq == 0) {
+      psum[wave][col][0] = s1;
+      psum[wave][col][1] = s2;
+    }
+  }
+  __syncthreads();
+  // ---- phase B: 16 lanes per token (lane l owns experts l, l+16, ..): finish the logits, softmax + top-1 with
+  //      the reference's arg-max tree (strides >= 16 inside the lane, 8/4/2/1 across lanes by DPP row shifts) ----
+  constexpr int EPL = E / 16;                    // experts per lane
+  for (int tok0 = 0; tok0 < S; tok0 += 4 * NWV) {
+    const int tok = tok0 + (tid >> 4);
+    const int l16 = tid & 15;
+    const int tk = min(tok, S - 1);
+    const int t = tk >> 4, r = tk & 15;
+    float t1 = 0.f, t2 = 0.f;
+    for (int p = 0; p < KP; ++p) {
+      t1 += psum[t * KP + p][r][0];
+      t2 += psum[t * KP + p][r][1];
+    }
+    const float mean = t1 / (float)D;
+    const float rstd = rsqrtf(fmaxf(t2 / (float)D - mean * mean, 0.f) + ln_eps);
+    float v[EPL], c[EPL];
+    int id[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const int e = l16 + 16 * j;
+      float a = 0.f;
+      for (int p = 0; p < KP; ++p) a += part[t * KP + p][r][e];
+      const float ev = (tok0 == 0) ? epre[j] : (eall ? eall[(size_t)tk * ld_e + e] : 0.f);
+      v[j] = rstd * (a - mean * s_wsum[e]) + s_bias[e] + ev;
+      c[j] = v[j];
+      id[j] = e;
+    }
+#pragma unroll
+    for (int stride = EPL / 2; stride > 0; stride >>= 1)   // tree strides E/2 .. 16: partners live in this lane
+#pragma unroll
+      for (int j = 0; j < stride; ++j)
+        if (c[j] < c[j + stride]) {
+          c[j] = c[j + stride];
+          id[j] = id[j + stride];
+        }
+    float best = c[0];
+    int bi = id[0];
+#define M3_TREE_STEP(STRIDE, CTRL)                                                            \
+    {                                                                                         \
+      const float ov = dpp_mov<CTRL>(best);                                                   \
+      const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, true);                \
+      if (l16 < STRIDE && best < ov) {                                                        \
+        best = ov;                                                                            \
+        bi = oi;                                                                              \
+      }                                                                                       \
+    }
+    M3_TREE_STEP(8, 0x108)   // row_shl:8  -> lane l reads lane l+8
+    M3_TREE_STEP(4, 0x104)
+    M3_TREE_STEP(2, 0x102)
+    M3_TREE_STEP(1, 0x101)
+#undef M3_TREE_STEP
+    const float mx = __shfl(best, (tid & 63) & ~15, 64);     // lane 0 of the 16-lane group holds the winner
+    const int mi = __shfl(bi, (tid & 63) & ~15, 64);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) sum += expf(v[j] - mx);
+    sum = group16_sum(sum);
+    if (tok < S && l16 == 0) {
+      const bool live = row_len == nullptr || (tok % rows_per_batch) < row_len[tok / rows_per_batch];
+      gate_idx[tok] = live ? mi : -1;
+      gate_value[tok] = live ? 1.f / sum : 0.f;
+      s_gate[tok] = live ? mi : -1;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: stable counting sort by expert ----
+  moe_index_body(s_gate, S, E, nbits, mapping, acc_hist, pos);
+}
+
+int launch_moe_route(const float* x, int ldx, int D, const float* wx, const float* wsum, const float* bias,
+                     const float* eall, int ld_e, float ln_eps, const int32_t* row_len, int rows_per_batch, int S, int E,
+                     int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
+                     hipStream_t stream) {
+  M3_REQUIRE(S > 0 && S <= 256, "moe_route: S=%d outside [1,256]", S);
+  M3_REQUIRE((D & 15) == 0 && (ldx & 3) == 0, "moe_route: bad D / ldx");
+  M3_REQUIRE(row_len == nullptr || rows_per_batch > 0, "moe_route: rows_per_batch missing");
+  int nbits = 0;
+  while ((1 << nbits) < E) ++nbits;
+#define M3_ROUTE_CASE(E_)                                                                                          \
+  hipLaunchKernelGGL((moe_route_kernel<E_, 16>), dim3(1), dim3(1024), 0, stream, x, ldx, D, wx, wsum, bias,       \
+                     eall, ld_e, ln_eps, row_len, rows_per_batch, S, nbits, gate_idx, gate_value, mapping, acc_hist, pos)
+  switch (E) {
+    case 16: M3_ROUTE_CASE(16); break;
+    case 32: M3_ROUTE_CASE(32); break;
+    case 64: M3_ROUTE_CASE(64); break;
+    default: M3_REQUIRE(false, "moe_route: num_expert=%d must be 16/32/64", E);
+  }
+#undef M3_ROUTE_CASE
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -42,7 +42,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "input_dim", "output_dim", "attention_dim", "attention_heads", "num_blocks",
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
-        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps")]
+        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "fuse_route")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry

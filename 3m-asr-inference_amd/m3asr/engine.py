@@ -15,7 +15,7 @@ from .config import EncoderConfig, subsampled_len
 from .plan import pack_weights
 
 
-def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps):
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=True):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -27,12 +27,13 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps):
     ec.embed_cnn_layer_norm = int(cfg.embed_cnn_module_norm == "layer_norm")
     ec.router_with_bias, ec.keep_expert_output = int(cfg.router_with_bias), int(cfg.keep_expert_output)
     ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
-    ec.fold_pos_proj, ec.debug_taps = int(fold_pos_proj), int(debug_taps)
+    ec.fold_pos_proj, ec.debug_taps, ec.fuse_route = int(fold_pos_proj), int(debug_taps), int(fuse_route)
     return ec
 
 
 class Engine:
-    def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False):
+    def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False,
+                 fuse_route=True):
         """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine)."""
@@ -50,7 +51,7 @@ class Engine:
             table[i].name = self._keep[i]
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
-        ec = _engine_config(cfg, fold_pos_proj, debug_taps)
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps, fuse_route and cfg.ep_world_size <= 1)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())

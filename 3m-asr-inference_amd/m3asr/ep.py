@@ -110,6 +110,7 @@ class ExpertParallelEncoder:
 
     def __init__(self, engine, group=None):
         self.eng, self.group = engine, group
+        # needs the staged route path (router GEMM materialises xn; gate / index / expert / combine are separate stages)
         cfg = engine.cfg
         self.e_loc = cfg.num_experts
         self.backend = HipBackend()
@@ -129,6 +130,8 @@ class ExpertParallelEncoder:
         eng, cfg = self.eng, self.eng.cfg
         logits = eng.bind(feat, feat_len)
         names = eng.stage_names()
+        if "blocks.0.moe_router" not in names:
+            raise RuntimeError("ExpertParallelEncoder needs an engine built with fuse_route=False (or ep_world_size > 1)")
         S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
         cur = 0
         with torch.cuda.stream(eng.stream):

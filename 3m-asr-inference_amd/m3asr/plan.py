@@ -117,6 +117,12 @@ def _pack_block(sd, p, out, norm, moe, cfg):
         out[f + "w_2.bias"] = sd[f + "w_2.bias"]
     else:
         out[f + "router_weights_t"] = sd[f + "router_weights"].t().contiguous()
+        # fused route path: the x half of the router with norm_ff folded in (the embed half of all layers is stacked
+        # into router_e_all by pack_weights)
+        De_ = sd[f + "router_weights"].shape[0] - sd[p + "norm_ff.weight"].shape[0]
+        rb = sd[f + "router_bias"] if (f + "router_bias") in sd else torch.zeros(sd[f + "router_weights"].shape[1])
+        _put_folded(out, f + "router_x.", fold_layernorm(sd[f + "router_weights"][De_:].t().contiguous(), rb,
+                                                         sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"]))
         if (f + "router_bias") in sd:
             out[f + "router_bias"] = sd[f + "router_bias"]
         lo = cfg.ep_rank * cfg.num_experts if cfg.ep_world_size > 1 else 0
@@ -148,6 +154,8 @@ def pack_weights(state_dict, cfg: EncoderConfig):
         _pack_block(sd, "blocks.%d." % i, out, cfg.cnn_module_norm, True, cfg)
     _put_folded(out, "out_linear.", fold_layernorm(sd["out_linear.weight"], sd["out_linear.bias"],
                                                    sd["after_norm.weight"], sd["after_norm.bias"]))
+    out["router_e_all.weight"] = torch.cat(
+        [sd["blocks.%d.feed_forward.router_weights" % i][:cfg.embed_dim].t() for i in range(cfg.num_blocks)], 0).contiguous()
     out["pe"] = positional_table(cfg.max_len, cfg.attention_dim)
     # every block's linear_pos weight stacked: p for all blocks = one GEMM per forward (attention.py:345)
     out["pos_all.weight"] = torch.cat(

@@ -212,6 +212,7 @@ typedef struct m3_engine_config {
   int32_t ep_world_size, ep_rank; /* expert parallel: this rank owns experts [rank*E_loc, (rank+1)*E_loc) */
   int32_t fold_pos_proj;         /* 1 = linear_pos(pos_emb) computed once per T' at shape set-up */
   int32_t debug_taps;            /* 1 = keep every block's output (the reference's DumpTensor taps) */
+  int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank) */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

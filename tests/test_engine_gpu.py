@@ -83,6 +83,23 @@ def test_engine_graph_replay_and_fold_are_bit_identical():
     assert eng2.num_kernels() < eng.num_kernels()
 
 
+def test_fused_and_staged_route_paths_agree():
+    """fuse_route=1 (router + SoftmaxTopK + ScatterMapping in one launch, LayerNorm applied by the expert kernel) vs the
+    staged path (router GEMM writes xn, separate gate+index): same routing decisions, logits within fp32 noise."""
+    cfg = EncoderConfig(num_blocks=3, embed_blocks=1)
+    w = make_weights(cfg, seed=8)
+    feat = torch.rand(2, 206, cfg.input_dim, generator=torch.Generator().manual_seed(3)).cuda()
+    fl = torch.tensor([[206, 131]], dtype=torch.int32).cuda()
+    a = Engine.from_state_dict(cfg, w, fuse_route=True)
+    b = Engine.from_state_dict(cfg, w, fuse_route=False)
+    ya, yb = a(feat, fl).clone(), b(feat, fl).clone()
+    assert "blocks.0.moe_route" in a.stage_names() and "blocks.0.moe_router" in b.stage_names()
+    assert a.num_kernels() < b.num_kernels()
+    for i in range(cfg.num_blocks):
+        assert torch.equal(a.buffer("blocks.%d.gate_idx" % i, torch.int32), b.buffer("blocks.%d.gate_idx" % i, torch.int32))
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()

@@ -25,9 +25,13 @@ def test_ep_world1_equals_fused_engine():
     w = make_weights(cfg, seed=4)
     feat = torch.rand(2, 120, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
     fl = torch.tensor([[120, 77]], dtype=torch.int32).cuda()
-    fused = Engine.from_state_dict(cfg, w)(feat, fl).clone()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w))
-    assert torch.equal(ep.forward(feat, fl), fused)
+    # the EP driver replaces the moe_local.* stages of the staged (unfused-route) engine: same kernels, same order
+    staged = Engine.from_state_dict(cfg, w, fuse_route=False)(feat, fl).clone()
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False))
+    assert torch.equal(ep.forward(feat, fl), staged)
+    # the default engine fuses router + top-1 + index into one launch (different summation order in the router)
+    fused = Engine.from_state_dict(cfg, w)(feat, fl)
+    assert torch.allclose(fused, staged, rtol=1e-4, atol=1e-4)
 
 
 def _worker(rank, world, port, out_dir):
@@ -40,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     T = 90 if rank == 0 else 61
     feat = torch.randn(2, T, cfg.input_dim, generator=g)
     fl = torch.tensor([[T, T - 20]], dtype=torch.int32)
-    eng = Engine.from_state_dict(cfg, w, device="cuda:0")
+    eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path
     out = ExpertParallelEncoder(eng).forward(feat.cuda(), fl.cuda()).cpu()
     want = encoder_forward(w, full, feat, fl)
     valid = torch.arange(out.shape[1]).view(1, -1) < sub_len(fl.view(-1).long()).view(-1, 1)
