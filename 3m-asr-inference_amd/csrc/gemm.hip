@@ -45,7 +45,9 @@ constexpr int gemm_group_steps(int MT, int NT, int NW) {
 enum { LN_NONE = 0, LN_EPI = 1, LN_PRO = 2 };
 
 // NW = waves per workgroup = K-split factor (4 / 8 / 16 for K ~ 512 / 1024 / >= 2048).
-template <int MT, bool GLU, int NW, bool CONV, int LN>
+// NBUF = 1 when a wave's share of K fits one load group (K <= 16*NW*G: every block GEMM of the model): half the
+// staging registers -> <= 128 VGPRs -> 4 waves per SIMD, so kernels of other streams can share the CU.
+template <int MT, bool GLU, int NW, bool CONV, int LN, int NBUF>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   constexpr int NT = GLU ? 2 : 1;
   constexpr int G = gemm_group_steps(MT, NT, NW);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   };
 
   // two groups of G K-steps in flight (registers only; nothing is shared between waves)
-  f32x4 wbuf[2][G][NT], abuf[2][G][MT];
+  f32x4 wbuf[NBUF][G][NT], abuf[NBUF][G][MT];
   auto load_group = [&](int g, int buf) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
@@ -267,12 +269,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
     }
   };
 
-  for (int g = 0; g < ngroups; g += 2) {
-    if (g + 1 < ngroups) load_group(g + 1, 1);
-    compute_group(g, 0);
-    if (g + 1 < ngroups) {
-      if (g + 2 < ngroups) load_group(g + 2, 0);
-      compute_group(g + 1, 1);
+  if (NBUF == 1) {
+    compute_group(0, 0);
+  } else {
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load_group(g + 1, NBUF - 1);
+      compute_group(g, 0);
+      if (g + 1 < ngroups) {
+        if (g + 2 < ngroups) load_group(g + 2, 0);
+        compute_group(g + 1, NBUF - 1);
+      }
     }
   }
 
@@ -389,8 +395,13 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   if (nw == 16 && (glu || mt == 4)) nw = 8;   // those 16-wave variants would spill registers
   if (nw == 16 && ln != LN_NONE) nw = 8;
 
-#define M3_GEMM_LAUNCH(MT_, GLU_, NW_, CONV_, LN_) \
-  hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_, NW_, CONV_, LN_>), grid, dim3(64 * NW_), 0, stream, p)
+#define M3_GEMM_LAUNCH(MT_, GLU_, NW_, CONV_, LN_)                                                              \
+  do {                                                                                                          \
+    if ((p.K >> 4) <= NW_ * gemm_group_steps(MT_, GLU_ ? 2 : 1, NW_))                                           \
+      hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_, NW_, CONV_, LN_, 1>), grid, dim3(64 * NW_), 0, stream, p); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((gemm_f32_kernel<MT_, GLU_, NW_, CONV_, LN_, 2>), grid, dim3(64 * NW_), 0, stream, p); \
+  } while (0)
 #define M3_GEMM_MT(GLU_, NW_, CONV_, LN_)                                                              \
   do {                                                                                                 \
     if (mt == 1) M3_GEMM_LAUNCH(1, GLU_, NW_, CONV_, LN_);                                             \

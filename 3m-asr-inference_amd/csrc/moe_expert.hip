@@ -24,7 +24,9 @@
 
 namespace m3 {
 
-template <int MT>
+// LNS: apply the layer's LayerNorm while gathering rows (fused-route engines); a separate instantiation so the
+// default path does not carry its registers.
+template <int MT, bool LNS>
 __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kernel(const float* __restrict__ x, int ldx,
                                                              const int32_t* __restrict__ pos,
                                                              const int32_t* __restrict__ acc_hist, int S, int D,
@@ -96,28 +98,41 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
       float* dst = xs + i * xs_ld;
       if (i < nrows) {
         const float* src = x + (size_t)pos[r0 + i] * ldx;
-        if (ln_gamma != nullptr) {
+        if (LNS) {
           // the layer's LayerNorm (norm_ff) applied on the fly: x is the raw residual stream and the normalised
           // MoE input never exists in memory (two-pass statistics; the row is L1/L2-resident)
+          f32x4 v[8];                              // the row stays in registers: one memory round trip (D <= 2048)
           float s = 0.f;
-          for (int c = lane * 4; c < D; c += 256) {
-            const f32x4 v = ldg4(src + c);
-            s += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = lane * 4 + 256 * j;
+            const f32x4 t = ldg4(src + min(c, D - 4));
+            const bool in = c < D;
+            v[j] = f32x4{in ? t[0] : 0.f, in ? t[1] : 0.f, in ? t[2] : 0.f, in ? t[3] : 0.f};
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
           }
           const float mean = wave_sum(s) / (float)D;
           float q = 0.f;
-          for (int c = lane * 4; c < D; c += 256) {
-            const f32x4 v = ldg4(src + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q += (v[j] - mean) * (v[j] - mean);
+          for (int j = 0; j < 8; ++j) {
+            const float on = (lane * 4 + 256 * j < D) ? 1.f : 0.f;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const float d = (v[j][e4] - mean) * on;
+              q += d * d;
+            }
           }
           const float rstd = rsqrtf(wave_sum(q) / (float)D + ln_eps);
-          for (int c = lane * 4; c < D; c += 256) {
-            const f32x4 v = ldg4(src + c), g = ldg4(ln_gamma + c), be = ldg4(ln_beta + c);
-            f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * g[j] + be[j];
-            stg4(dst + c, o);
+          for (int j = 0; j < 8; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < D) {
+              const f32x4 g = ldg4(ln_gamma + c), be = ldg4(ln_beta + c);
+              f32x4 o;
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4) o[e4] = (v[j][e4] - mean) * rstd * g[e4] + be[e4];
+              stg4(dst + c, o);
+            }
           }
         } else {
           for (int c = lane * 4; c < D; c += 256) stg4(dst + c, ldg4(src + c));
@@ -207,10 +222,10 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
 int init_expert_ffn_kernels() {
   static bool done = false;
   if (done) return 0;
-  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   done = true;
   return 0;
 }
@@ -234,11 +249,13 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   const int w2_row_stride = w2_sliced ? kExpertSlice : F;
   const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
   if (int rc = init_expert_ffn_kernels()) return rc;
-#define M3_EXPERT_CASE(MT_)                                                                             \
-  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, pos,    \
+#define M3_EXPERT_CASE2(MT_, LNS_)                                                                      \
+  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_, LNS_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, pos,    \
                      acc_hist, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab, ln_gamma, ln_beta, ln_eps)
+#define M3_EXPERT_CASE(MT_) do { if (ln_gamma) M3_EXPERT_CASE2(MT_, true); else M3_EXPERT_CASE2(MT_, false); } while (0)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
 #undef M3_EXPERT_CASE
+#undef M3_EXPERT_CASE2
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -15,7 +15,7 @@ from .config import EncoderConfig, subsampled_len
 from .plan import pack_weights
 
 
-def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=True):
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -33,7 +33,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Tru
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False,
-                 fuse_route=True):
+                 fuse_route=False):
         """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine)."""

@@ -26,6 +26,10 @@ for p in (ROOT, os.path.join(ROOT, "3m-asr-inference_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the execution contexts of --streams need one
+# each, so ask for 8 before the runtime initialises (a process-level runtime knob, not a machine setting)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -43,13 +47,16 @@ def parse():
     ap.add_argument("--fold-pos", action="store_true", help="precompute linear_pos(pos_emb) per shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="concurrent execution contexts per GPU (each its own utterance, stream, workspace and hipGraph, "
                          "weights shared); batch stays 1 per context")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the CPU baseline (0 = min(32, cores))")
     ap.add_argument("--routing", choices=["balanced", "random"], default="balanced",
                     help="balanced: calibrate the synthetic router weights so tokens spread over the experts "
                          "(a trained 3M-ASR router is load-balanced by its aux losses); random: raw N(0,0.5) init")
+    ap.add_argument("--fuse-route", action="store_true",
+                    help="router + SoftmaxTopK + ScatterMapping as one single-workgroup launch per layer (275 instead of "
+                         "292 kernels; measured 2-3 %% slower than the staged path, so off by default)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
     return ap.parse_args()
 
@@ -103,6 +110,8 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    if world > 1:      # host-side weight generation / packing: do not oversubscribe the cores with N ranks x all threads
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
@@ -120,15 +129,15 @@ def main():
     feat_cpu = torch.from_numpy(rng.random((B, T, cfg.input_dim), dtype=np.float32))
     feat = feat_cpu.to(dev)
     feat_len = torch.full((1, B), T, dtype=torch.int32, device=dev)
+    # the staged-route engine exposes xn / the router stage, which the synthetic-router calibration needs
+    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False)
     if args.routing == "balanced":
-        # calibrate the synthetic router on a staged-route engine (it exposes xn / router stages), write the result
-        # back into the state_dict, then build the engine that is timed from it
-        cal = Engine.from_state_dict(cfg, weights, device=dev, fuse_route=False)
-        cal.bind(feat, feat_len)
-        balance_router(cal, weights)
-        del cal
+        eng.bind(feat, feat_len)
+        balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
+    if args.fuse_route:                      # rebuild from the calibrated state_dict
+        del eng
         torch.cuda.empty_cache()
-    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos)
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=True)
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         weights = None
     eng.bind(feat, feat_len)
@@ -138,7 +147,7 @@ def main():
     # extra execution contexts: same weights, own utterance / stream / workspace / graph
     ctxs = [eng]
     for si in range(1, args.streams):
-        c = eng.clone_context(fold_pos_proj=args.fold_pos)
+        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=args.fuse_route)
         f2 = torch.from_numpy(np.random.default_rng(5000 + 97 * rank + si).random((B, T, cfg.input_dim), dtype=np.float32)).to(dev)
         c.bind(f2, feat_len.clone())
         ctxs.append(c)

@@ -29,8 +29,8 @@ def test_ep_world1_equals_fused_engine():
     staged = Engine.from_state_dict(cfg, w, fuse_route=False)(feat, fl).clone()
     ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False))
     assert torch.equal(ep.forward(feat, fl), staged)
-    # the default engine fuses router + top-1 + index into one launch (different summation order in the router)
-    fused = Engine.from_state_dict(cfg, w)(feat, fl)
+    # fuse_route engines do router + top-1 + index in one launch (different summation order in the router)
+    fused = Engine.from_state_dict(cfg, w, fuse_route=True)(feat, fl)
     assert torch.allclose(fused, staged, rtol=1e-4, atol=1e-4)
 
 
