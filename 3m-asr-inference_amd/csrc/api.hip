@@ -131,7 +131,21 @@ int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, cons
 }
 int m3_subsample_conv1(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
                        float* out, m3_stream stream) {
-  return launch_conv1_relu(feat, w9c, bias, B, T, idim, C, out, (hipStream_t)stream);
+  return launch_conv1_relu(feat, w9c, bias, nullptr, nullptr, B, T, idim, C, out, (hipStream_t)stream);
+}
+int m3_subsample_conv1_cmvn(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
+                            const float* cmvn_istd, int B, int T, int idim, int C, float* out, m3_stream stream) {
+  M3_REQUIRE((cmvn_mean == nullptr) == (cmvn_istd == nullptr), "subsample_conv1: cmvn mean and istd go together");
+  return launch_conv1_relu(feat, w9c, bias, cmvn_mean, cmvn_istd, B, T, idim, C, out, (hipStream_t)stream);
+}
+int m3_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D, float* y,
+            m3_stream stream) {
+  M3_REQUIRE(x && mean && istd && y, "cmvn: null pointer");
+  return launch_cmvn(x, len, mean, istd, B, T, D, y, (hipStream_t)stream);
+}
+int m3_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, m3_stream stream) {
+  M3_REQUIRE(x && y && n > 0, "log_softmax_bias: bad arguments");
+  return launch_log_softmax_bias(x, bias, y, rows, n, (hipStream_t)stream);
 }
 int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, float* out,
                        m3_stream stream) {

@@ -103,8 +103,12 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
 }
 
 // feat [B][T][idim] -> out [B][T1][F1][C] (channel-last), w9c [9][C] (repacked from (C,1,3,3)), ReLU.
+// Optional global CMVN folded into the read: x <- (x - mean[f]) * istd[f]   (the reference's unfinished CmvnPlugin,
+// incomplete_plugin/cmvn_plugin/cmvn_plugin.cu:17-43; builder.sh:9 passes --cmvn_file but builder.py ignores it).
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ feat, const float* __restrict__ w9c,
-                                                         const float* __restrict__ bias, int T, int idim, int T1,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ cmvn_mean,
+                                                         const float* __restrict__ cmvn_istd, int T, int idim, int T1,
                                                          int F1, int C, float* __restrict__ out, size_t n4) {
   const int c4n = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const float xv = base[kh * idim + kw];
+        float xv = base[kh * idim + kw];
+        if (cmvn_mean != nullptr) xv = (xv - cmvn_mean[2 * f1 + kw]) * cmvn_istd[2 * f1 + kw];
         const f32x4 w = ldg4(w9c + (kh * 3 + kw) * C + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
@@ -131,14 +136,14 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
   }
 }
 
-int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
-                      float* out, hipStream_t stream) {
+int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream) {
   M3_REQUIRE(T >= 3 && idim >= 3, "subsampling: input (T=%d, idim=%d) shorter than the 3x3 kernel", T, idim);
   M3_REQUIRE((C & 3) == 0, "subsampling: channels=%d must be a multiple of 4", C);
   const int T1 = (T - 3) / 2 + 1, F1 = (idim - 3) / 2 + 1;
   const size_t n4 = (size_t)B * T1 * F1 * (C / 4);
   hipLaunchKernelGGL(conv1_relu_kernel, dim3(grid1d(n4, 4096)), dim3(256), 0, stream,
-                     feat, w9c, bias, T, idim, T1, F1, C, out, n4);
+                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4);
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -68,6 +68,8 @@ struct m3_engine {
   const float* pe = nullptr;
   int64_t pe_rows = 0;
   const float* pos_all = nullptr;   // [(embed_blocks + num_blocks) * D][D]: every block's linear_pos weight
+  const float* cmvn_mean = nullptr; const float* cmvn_istd = nullptr;   // optional global CMVN (fused into conv1)
+  const float* output_bias = nullptr;                                     // optional [V] added to the output (-log prior)
   const float* router_e_all = nullptr;   // [num_blocks * E][De]: embed half of every layer's router (fused route path)
 
   // bound shape
@@ -243,7 +245,8 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   const float* feat = e->feat;
   float* c1 = pl.c1; float* c2 = pl.c2;
   const int idim = c.input_dim;
-  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, B, T, idim, D, c1, s); });
+  const float* cm = e->cmvn_mean; const float* ci = e->cmvn_istd;
+  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s); });
   GemmParams g;
   g.mode = GEMM_A_CONV3X3S2; g.A = c1; g.lda = 4;
   g.conv_T1 = T1; g.conv_F1 = F1; g.conv_T2 = T2; g.conv_F2 = F2; g.conv_C = D;
@@ -430,6 +433,19 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   if (!load_norm(e, "embed.after_norm.", De, &e->e_after) ||
       !load_lin_ln(e, "out_linear.", c.output_dim, D, false, &e->out_linear))
     return fail(nullptr);
+  {   // optional front / back end tensors
+    auto m = e->table.find("cmvn.mean"), v = e->table.find("cmvn.istd"), ob = e->table.find("output_bias");
+    if ((m == e->table.end()) != (v == e->table.end())) return fail("engine_create: cmvn.mean and cmvn.istd go together");
+    if (m != e->table.end()) {
+      if (m->second.numel != c.input_dim || v->second.numel != c.input_dim) return fail("engine_create: cmvn vectors must have input_dim entries");
+      e->cmvn_mean = (const float*)m->second.data;
+      e->cmvn_istd = (const float*)v->second.data;
+    }
+    if (ob != e->table.end()) {
+      if (ob->second.numel != c.output_dim) return fail("engine_create: output_bias must have output_dim entries");
+      e->output_bias = (const float*)ob->second.data;
+    }
+  }
   {
     auto it = e->table.find("pe");
     if (it == e->table.end() || it->second.numel % D) return fail("engine_create: positional table 'pe' missing");
@@ -526,6 +542,11 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     g.M = S; g.N = c.output_dim; g.K = D;
     g.ln_wsum = e->out_linear.wsum; g.ln_eps = 1e-12f;       // after_norm is folded into out_linear
     add_gemm(e, "logits", g);
+    const float* ob = e->output_bias;
+    const int V = c.output_dim;
+    if (c.log_softmax_out) {
+      add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(logits, ob, logits, (size_t)S, V, s); });
+    }   // without log-softmax a prior is folded into out_linear's bias when the plan is packed (plan.py)
   }
   e->buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};

@@ -184,6 +184,48 @@ int launch_softmax_lastdim(const float* x, float* y, size_t rows, int n, hipStre
   return 0;
 }
 
+// y = log_softmax(x) + bias  per row (bias may be null).  The acoustic-score back end the reference sketches:
+// log-softmax commented out in builder.py:77-81, "- log prior" in builder.py:83-88, fused form in
+// incomplete_plugin/prior_prob_plugin/prior_prob_kernel.cu:11-26 (log(p + 1e-20) + log_prior).
+__global__ void log_softmax_bias_kernel(const float* x, const float* __restrict__ bias, float* y, size_t rows, int n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const float* xr = x + row * n;
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, xr[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) sum += expf(xr[j] - mx);
+  const float lse = mx + logf(wave_sum(sum));
+  for (int j = lane; j < n; j += 64) y[row * n + j] = xr[j] - lse + (bias ? bias[j] : 0.f);
+}
+int launch_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, hipStream_t stream) {
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(log_softmax_bias_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, bias, y, rows, n);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// global CMVN on (B,T,D) features, frames t < len[b] only (cmvn_plugin.cu:17-34); len may be null
+__global__ void cmvn_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, const float* __restrict__ mean,
+                            const float* __restrict__ istd, int T, int D, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % T);
+    const int b = (int)(i / ((size_t)D * T));
+    y[i] = (len == nullptr || t < len[b]) ? (x[i] - mean[d]) * istd[d] : x[i];
+  }
+}
+int launch_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D, float* y,
+                hipStream_t stream) {
+  const size_t n = (size_t)B * T * D;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cmvn_kernel, dim3(grid1d(n, 2048)), dim3(256), 0, stream, x, len, mean, istd, T, D, y, n);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- masked_fill on (B,C,T)
 __global__ void masked_fill_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, int C, int T,
                                    float fill, float* __restrict__ y, size_t n) {
@@ -251,7 +293,7 @@ int launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s
 __global__ void unary_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float v = x[i];
-    y[i] = act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_SILU ? silu(v) : (act == 4 ? sigmoidf(v) : v));
+    y[i] = act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_SILU ? silu(v) : (act == 4 ? sigmoidf(v) : (act == 5 ? logf(v) : v)));
   }
 }
 int launch_unary(const float* x, float* y, size_t n, int act, hipStream_t stream) {

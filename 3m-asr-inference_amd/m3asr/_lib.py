@@ -42,7 +42,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "input_dim", "output_dim", "attention_dim", "attention_heads", "num_blocks",
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
-        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "fuse_route")]
+        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
@@ -51,7 +51,7 @@ class WeightEntry(C.Structure):  # m3_weight_entry
 
 FIELD_FLOAT32, FIELD_INT32 = 1, 5
 F32, F16, I8, I32, BF16 = 0, 1, 2, 3, 4
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_GLU, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GLU, ACT_SIGMOID, ACT_LOG = 0, 1, 2, 3, 4, 5
 OP_SUM, OP_PROD = 0, 1
 
 _vp, _i, _f, _sz, _i64, _cp = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64, C.c_char_p
@@ -90,6 +90,9 @@ SIGNATURES = {
     "m3_relpos_attention": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "m3_dwconv_ln_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "m3_subsample_conv1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "m3_subsample_conv1_cmvn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "m3_cmvn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "m3_log_softmax_bias": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "m3_subsample_conv2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "m3_att_masked_softmax": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "m3_masked_fill": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),

@@ -33,6 +33,7 @@ class EncoderConfig:
     ep_world_size: int = 1
     ep_rank: int = 0
     max_len: int = 5000            # positional_encoding.py:31
+    log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
 
     @property
     def d_k(self):

@@ -28,6 +28,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.router_with_bias, ec.keep_expert_output = int(cfg.router_with_bias), int(cfg.keep_expert_output)
     ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
     ec.fold_pos_proj, ec.debug_taps, ec.fuse_route = int(fold_pos_proj), int(debug_taps), int(fuse_route)
+    ec.log_softmax_out = int(cfg.log_softmax_out)
     return ec
 
 

@@ -181,6 +181,22 @@ def subsample_conv1(feat, w9c, bias):
     return out
 
 
+def cmvn(x, lens, mean, istd):
+    lib = _lib.load()
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    check(lib.m3_cmvn(_f32(x), _i32(lens), _f32(mean), _f32(istd), B, T, D, _p(y), _stream()), "m3_cmvn")
+    return y
+
+
+def log_softmax_bias(x, bias=None):
+    lib = _lib.load()
+    n = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.m3_log_softmax_bias(_f32(x), _f32(bias), _p(y), x.numel() // n, n, _stream()), "m3_log_softmax_bias")
+    return y
+
+
 def subsample_conv2(x, w, bias):
     lib = _lib.load()
     B, T1, F1, Cc = x.shape

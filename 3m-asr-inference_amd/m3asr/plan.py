@@ -164,6 +164,39 @@ def pack_weights(state_dict, cfg: EncoderConfig):
     return OrderedDict((k, v.contiguous()) for k, v in out.items())
 
 
+def read_cmvn_stats(path):
+    """Global CMVN statistics -> (mean, istd) float32 vectors.  Accepts a Kaldi text matrix
+    ``[ sum_0 .. sum_{d-1} count \\n sumsq_0 .. sumsq_{d-1} 0 ]`` (what ``Cmvn.read_stats`` loads in
+    trainer_3m_fix/loader/cectc_lattice_loader.py:21-24, applied with norm_vars=True) or a 2 x d ``.npy`` of (mean, istd)."""
+    if path.endswith(".npy"):
+        a = np.load(path, allow_pickle=False).astype(np.float64)
+        return torch.from_numpy(a[0].astype(np.float32)), torch.from_numpy(a[1].astype(np.float32))
+    txt = open(path).read().replace("[", " ").replace("]", " ")
+    vals = np.array([float(v) for v in txt.split()], dtype=np.float64)
+    stats = vals.reshape(2, -1)
+    count = stats[0, -1]
+    mean = stats[0, :-1] / count
+    var = np.maximum(stats[1, :-1] / count - mean * mean, 1e-20)
+    return torch.from_numpy(mean.astype(np.float32)), torch.from_numpy((1.0 / np.sqrt(var)).astype(np.float32))
+
+
+def add_front_back_end(packed, cfg, cmvn=None, output_bias=None):
+    """Optional front / back end of the acoustic score, attached to a packed weight dict:
+    cmvn = (mean, istd) -> fused into the first subsampling conv of both encoders; output_bias [V] (e.g. -log prior,
+    builder.py:83-88) -> added after log_softmax when cfg.log_softmax_out, else folded into out_linear's bias."""
+    if cmvn is not None:
+        packed["cmvn.mean"] = torch.as_tensor(cmvn[0], dtype=torch.float32).contiguous()
+        packed["cmvn.istd"] = torch.as_tensor(cmvn[1], dtype=torch.float32).contiguous()
+    if output_bias is not None:
+        ob = torch.as_tensor(output_bias, dtype=torch.float32).flatten().contiguous()
+        assert ob.numel() == cfg.output_dim
+        if cfg.log_softmax_out:
+            packed["output_bias"] = ob
+        else:
+            packed["out_linear.ln.bias"] = packed["out_linear.ln.bias"] + ob
+    return packed
+
+
 def save_plan(path, cfg: EncoderConfig, packed, extra=None):
     index, off = {}, 0
     for k, v in packed.items():

@@ -12,7 +12,7 @@ import torch
 
 from m3asr import _lib
 from m3asr.engine import Engine
-from m3asr.plan import pack_weights, save_plan
+from m3asr.plan import pack_weights, save_plan, add_front_back_end
 from . import trt
 from .network_helper import NetworkHelper
 
@@ -119,13 +119,13 @@ class BuilderHelper:
         if not nh.outputs:
             raise RuntimeError("build_engine: no output marked")
         packed = pack_weights(self.model, self.model_cfg)
+        extra = getattr(self, "output_bias", None)            # e.g. -log prior (builder.py:83-88)
+        add_front_back_end(packed, self.model_cfg, cmvn=getattr(self, "cmvn", None), output_bias=extra)
         eng = Engine(self.model_cfg, packed, device=str(self.device))
-        feat, feat_len = nh.inputs["feat"], nh.inputs["feat_len"]
+        # the engine applies CMVN itself: feed it the raw features the emission normalised (builder.py sets feat_raw)
+        feat, feat_len = nh._bound.get("feat_raw", nh.inputs["feat"]), nh.inputs["feat_len"]
         fused = eng(feat, feat_len)
         ref = nh.outputs[-1]
-        extra = getattr(self, "output_bias", None)
-        if extra is not None:
-            fused = fused + extra.to(fused.device)
         lens = eng.buffer("lens", torch.int32).cpu()
         valid = (torch.arange(fused.shape[1]).view(1, -1) < lens.view(-1, 1)).to(fused.device)
         err = float(((fused - ref).abs() * valid.unsqueeze(-1)).max())
@@ -135,8 +135,7 @@ class BuilderHelper:
             raise RuntimeError("build_engine: fused engine disagrees with the emitted network (%.3e)" % err)
         if engine_name is not None:
             save_plan(engine_name, self.model_cfg, packed,
-                      extra={"profiles": {k: [list(s) for s in v] for k, v in self.profiles.items()},
-                             "output_bias": extra.flatten().tolist() if extra is not None else None})
+                      extra={"profiles": {k: [list(s) for s in v] for k, v in self.profiles.items()}})
             self.logger.log(trt.Logger.INFO, "[Builder] plan written to " + engine_name)
         names = list(nh.inputs) + ["output"]
         shapes = [tuple(-1 for _ in nh.inputs[n].shape) for n in nh.inputs] + [(-1, -1, self.model_cfg.output_dim)]

@@ -17,8 +17,7 @@ class InferHelper:
         cfg, packed, extra = load_plan(plan_name)
         self.cfg, self.extra = cfg, extra
         self.engine = Engine(cfg, packed, device=device)
-        ob = extra.get("output_bias")
-        self.output_bias = torch.tensor(ob, dtype=torch.float32, device=device).view(1, 1, -1) if ob else None
+        self.output_bias = None      # a prior is inside the plan (folded into out_linear or applied after log-softmax)
 
     def _run(self, feat, feat_len, use_graph):
         out = self.engine.forward(feat, feat_len, use_graph=use_graph)

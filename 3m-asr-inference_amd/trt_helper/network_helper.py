@@ -323,6 +323,9 @@ class NetworkHelper:
     def addSigmoid(self, x, layer_name=None, precision=None):
         return ops.unary(x, _lib.ACT_SIGMOID)
 
+    def addLog(self, x, layer_name=None, precision=None):
+        return ops.unary(x, _lib.ACT_LOG)
+
     def addSoftmax(self, x, dim=-1, layer_name=None, precision=None):
         if dim not in (-1, x.dim() - 1):
             raise RuntimeError("softmax on dim %d not support!" % dim)

@@ -51,8 +51,20 @@ def build_trt(model, args, input_dim, plan_name, prior=None, profile=None):
     (min_b, opt_b, max_b), (min_t, opt_t, max_t) = profile or ((1, 4, 6), (1, 500, 6100))   # reference :58-64
     builder_helper.add_profile("feat", (min_b, min_t, input_dim), (opt_b, opt_t, input_dim), (max_b, max_t, input_dim))
     builder_helper.add_profile("feat_len", (1, min_b), (1, opt_b), (1, max_b))
+    if args.cmvn_file:                              # global CMVN (the reference accepts the flag but never applies it)
+        from m3asr import ops
+        from m3asr.plan import read_cmvn_stats
+        mean, istd = read_cmvn_stats(args.cmvn_file)
+        builder_helper.cmvn = (mean, istd)
+        raw = feat.resolve() if hasattr(feat, "resolve") else feat
+        nh._bound["feat_raw"] = raw
+        feat = nh._bound["feat"] = ops.cmvn(raw, None, mean.to(raw.device), istd.to(raw.device))
+    if args.log_softmax:
+        model.encoder.cfg.log_softmax_out = True
     res = model.encoder(nh, feat, feat_len)
-    if prior is not None:                           # score = logits - log(prior)   (reference :83-88)
+    if args.log_softmax:                            # score = log_softmax(output)   (reference :77-81, commented out there)
+        res = nh.addLog(nh.addSoftmax(res, dim=-1))
+    if prior is not None:                           # score = score - log(prior)    (reference :83-88)
         torch_prior = torch.from_numpy(-np.log(prior)).float().view(1, 1, -1)
         builder_helper.output_bias = torch_prior
         res = nh.addAdd(res, nh.addConstant(torch_prior))
@@ -92,7 +104,9 @@ if __name__ == "__main__":
     p.add_argument("-o", "--output", required=True, help="The plan file to write")
     p.add_argument("-c", "--config", required=True, help="config file")
     p.add_argument("-prior", "--prior_file", required=False, help="prior file")
-    p.add_argument("-cmvn", "--cmvn_file", required=False, help="cmvn file (accepted, unused -- as in the reference)")
+    p.add_argument("-cmvn", "--cmvn_file", required=False, help="global CMVN stats (Kaldi text matrix or 2xD .npy); fused into the first conv")
+    p.add_argument("--log-softmax", dest="log_softmax", action="store_true",
+                   help="output log_softmax(logits) (- log prior) instead of raw logits (reference builder.py:77-81)")
     p.add_argument("-f", "--fp16", action="store_true")
     p.add_argument("-i", "--int8", action="store_true")
     p.add_argument("-t", "--strict", action="store_true")

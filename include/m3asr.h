@@ -28,7 +28,7 @@ typedef void* m3_stream; /* hipStream_t */
 enum m3_dtype { M3_F32 = 0, M3_F16 = 1, M3_I8 = 2, M3_I32 = 3, M3_BF16 = 4 };
 
 /* activation / element-wise codes shared by several entry points */
-enum m3_act { M3_ACT_NONE = 0, M3_ACT_RELU = 1, M3_ACT_SILU = 2, M3_ACT_GLU = 3, M3_ACT_SIGMOID = 4 };
+enum m3_act { M3_ACT_NONE = 0, M3_ACT_RELU = 1, M3_ACT_SILU = 2, M3_ACT_GLU = 3, M3_ACT_SIGMOID = 4, M3_ACT_LOG = 5 };
 enum m3_binop { M3_OP_SUM = 0, M3_OP_PROD = 1 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -166,9 +166,19 @@ int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, cons
 /* Conv2dSubsampling4 (subsampling.py:103-145) on channel-last data: conv1 (1->C, 3x3, s2) + ReLU. */
 int m3_subsample_conv1(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C,
                        float* out, m3_stream stream);
+/* the same with global CMVN folded into the input read (mean / istd [idim], may be NULL) */
+int m3_subsample_conv1_cmvn(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
+                            const float* cmvn_istd, int B, int T, int idim, int C, float* out, m3_stream stream);
 /* second conv (C->C, 3x3, s2) + ReLU as implicit GEMM: in (B,T1,F1,C) -> out (B,T2,F2,C); w [C][3][3][C]. */
 int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C,
                        float* out, m3_stream stream);
+
+/* Front / back end of the acoustic score.  Global CMVN: y = (x - mean[d]) * istd[d] on frames
+ * t < len[b] (the reference's unfinished CmvnPlugin, incomplete_plugin/cmvn_plugin/cmvn_plugin.cu:17-43).
+ * Score: y = log_softmax(x) + bias per row, bias = -log(prior) (builder.py:77-88, prior_prob_kernel.cu:11-26). */
+int m3_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D, float* y,
+            m3_stream stream);
+int m3_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, m3_stream stream);
 
 /* small plugins */
 int m3_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
@@ -212,6 +222,7 @@ typedef struct m3_engine_config {
   int32_t ep_world_size, ep_rank; /* expert parallel: this rank owns experts [rank*E_loc, (rank+1)*E_loc) */
   int32_t fold_pos_proj;         /* 1 = linear_pos(pos_emb) computed once per T' at shape set-up */
   int32_t debug_taps;            /* 1 = keep every block's output (the reference's DumpTensor taps) */
+  int32_t log_softmax_out;       /* 1 = output log_softmax(logits) (+ "output_bias" weight entry if present, e.g. -log prior) */
   int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank) */
 } m3_engine_config;
 

@@ -29,6 +29,23 @@ def sub_len(l):
     return (l - 3) // 2 + 1
 
 
+def cmvn(feat, lens, mean, istd):
+    """Global CMVN as the reference's unfinished CmvnPlugin states it (TRTAPI++/plugin/incomplete_plugin/cmvn_plugin/
+    cmvn_plugin.cu:17-34): out = (in - mean[d]) * var[d] on frames t < len[b], other frames untouched."""
+    B, T, _ = feat.shape
+    y = (feat - mean.view(1, 1, -1)) * istd.view(1, 1, -1)
+    if lens is None:
+        return y
+    valid = (torch.arange(T).view(1, T) < lens.view(B, 1)).unsqueeze(-1)
+    return torch.where(valid, y, feat)
+
+
+def score(logits, log_softmax=False, output_bias=None):
+    """Back end sketched in builder.py:77-88: optional log_softmax, then + (-log prior)."""
+    y = torch.log_softmax(logits, dim=-1) if log_softmax else logits
+    return y + output_bias.view(1, 1, -1) if output_bias is not None else y
+
+
 def subsample(feat, w, p):
     """Conv2dSubsampling4.forward (trainer_3m_fix/layer/subsampling.py:103-145):
     (B,T,idim) -> (B,1,T,idim) -> conv3x3 s2 + ReLU -> conv3x3 s2 + ReLU -> (B,T',C*F') -> Linear."""

@@ -110,3 +110,40 @@ def test_engine_rejects_bad_input():
     del w["blocks.0.norm_ff.weight"]
     with pytest.raises(KeyError):
         Engine.from_state_dict(cfg, w)
+
+
+def test_front_and_back_end_cmvn_prior_logsoftmax(tmp_path):
+    """global CMVN fused into the first conv, -log(prior) and log-softmax on the output."""
+    from m3asr.plan import pack_weights, add_front_back_end, read_cmvn_stats
+    from m3asr import ops
+    from oracle import encoder_ref as ref
+    cfg = EncoderConfig(num_blocks=1, embed_blocks=1)
+    w = make_weights(cfg, seed=6)
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(2, 90, cfg.input_dim, generator=g) * 3.0 + 5.0
+    fl = torch.tensor([[90, 61]], dtype=torch.int32)
+    # Kaldi-style stats file: [sum.. count ; sumsq.. 0]
+    n, x2 = 1000.0, torch.randn(1000, cfg.input_dim, generator=g).double() * 3.0 + 5.0
+    stats = torch.zeros(2, cfg.input_dim + 1, dtype=torch.float64)
+    stats[0, :-1], stats[0, -1], stats[1, :-1] = x2.sum(0), n, (x2 * x2).sum(0)
+    path = str(tmp_path / "cmvn.txt")
+    with open(path, "w") as f:
+        f.write(" [\n  " + " ".join("%.10g" % v for v in stats[0]) + "\n  " + " ".join("%.10g" % v for v in stats[1]) + " ]\n")
+    mean, istd = read_cmvn_stats(path)
+    assert torch.allclose(mean, x2.mean(0).float(), atol=1e-4) and torch.allclose(istd, (1 / x2.std(0, unbiased=False)).float(), rtol=1e-4)
+    prior = torch.rand(cfg.output_dim, generator=g) + 0.05
+    bias = -torch.log(prior / prior.sum())
+    close = lambda a, b: bool(((a - b).abs() <= 3e-4 + 1e-3 * b.abs()).all())
+    normed = ref.cmvn(feat, None, mean, istd)
+    logits = encoder_forward(w, cfg, normed, fl)
+    valid = (torch.arange(logits.shape[1]).view(1, -1) < sub_len(fl.view(-1).long()).view(-1, 1))
+    # standalone ops
+    assert torch.allclose(ops.cmvn(feat.cuda(), fl.view(-1).cuda(), mean.cuda(), istd.cuda()).cpu(),
+                          ref.cmvn(feat, fl.view(-1), mean, istd), atol=1e-5)
+    assert torch.allclose(ops.log_softmax_bias(logits.cuda(), bias.cuda()).cpu(), ref.score(logits, True, bias), atol=2e-5)
+    for log_softmax in (False, True):
+        c2 = EncoderConfig(**{**cfg.__dict__, "log_softmax_out": log_softmax})
+        packed = add_front_back_end(pack_weights(w, c2), c2, cmvn=(mean, istd), output_bias=bias)
+        out = Engine(c2, packed)(feat.cuda(), fl.cuda()).cpu()
+        want = ref.score(logits, log_softmax, bias)
+        assert close(out[valid], want[valid]), float((out - want).abs()[valid].max())
