@@ -39,10 +39,10 @@ MoeWorkspace carve_moe_workspace(void* base, int S, int E, int D, int F) {
   return w;
 }
 
-int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
-                   const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
-                   float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
-                   size_t ws_bytes, hipStream_t stream) {
+int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
+                      const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
+                      float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
+                      size_t ws_bytes, hipStream_t stream, int w_bf16) {
   M3_REQUIRE(S >= 0 && E > 0 && D > 0 && F > 0, "fmoe_expert: bad sizes S=%d E=%d D=%d F=%d", S, E, D, F);
   if (S == 0) return 0;
   MoeWorkspace w = carve_moe_workspace(ws, S, E, D, F);
@@ -50,10 +50,19 @@ int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, con
              w.bytes);
   int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
   if (rc) return rc;
-  rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
+  if (w_bf16) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
+  else rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
   if (rc) return rc;
   return launch_moe_combine(w.slab, F / kExpertSlice, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma,
                             ln_beta, ln_eps, y, S, D, stream);
+}
+
+int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
+                   float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  return moe_expert_ffn_dt(x, gate_idx, w1, b1, w2, b2, S, E, D, F, gate_value, resid, alpha, ln_gamma, ln_beta, ln_eps,
+                           y, ws, ws_bytes, stream, 0);
 }
 
 }  // namespace m3
@@ -88,6 +97,14 @@ int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, 
   return moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, S, num_expert, idim, hidden_units, gate_value, resid, alpha,
                         ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes, (hipStream_t)stream);
 }
+int m3_moe_expert_ffn_bf16(const float* x, const int32_t* gate_idx, const void* w1, const float* b1, const void* w2,
+                           const float* b2, int S, int num_expert, int idim, int hidden_units, const float* gate_value,
+                           const float* resid, float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                           float* y, void* workspace, size_t workspace_bytes, m3_stream stream) {
+  return moe_expert_ffn_dt(x, gate_idx, (const float*)w1, b1, (const float*)w2, b2, S, num_expert, idim, hidden_units,
+                           gate_value, resid, alpha, ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes,
+                           (hipStream_t)stream, 1);
+}
 int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid, float alpha,
                    const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int idim,
                    m3_stream stream) {
@@ -106,7 +123,9 @@ int m3_linear(const m3_linear_desc* d, m3_stream stream) {
   p.A = d->a; p.lda = d->lda;
   p.A2 = d->a2; p.lda2 = d->lda2; p.K1 = d->k1;
   p.mode = d->a2 ? GEMM_A_CONCAT2 : GEMM_A_PLAIN;
-  p.W = d->w; p.bias = d->bias; p.Y = d->y; p.ldy = d->ldy;
+  p.W = (const float*)d->w; p.bias = d->bias; p.Y = d->y; p.ldy = d->ldy;
+  M3_REQUIRE(d->weight_dtype == M3_F32 || d->weight_dtype == M3_BF16, "linear: weight_dtype %d", d->weight_dtype);
+  p.w_bf16 = d->weight_dtype == M3_BF16;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_eps = d->ln_eps;
   p.ln_wsum = d->ln_wsum; p.ln_wbeta = d->ln_wbeta;

@@ -86,4 +86,25 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 operands (weights stored bf16, activations rounded at the MFMA input, fp32 accumulate) ----
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 ldg8h(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// 8 consecutive floats -> 8 bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[j] = (bf16_t)lo[j];
+    r[4 + j] = (bf16_t)hi[j];
+  }
+  return r;
+}
+// D = A(16x32) * B(32x16) + C (v_mfma_f32_16x16x32_bf16).
+// lane l: a[j] = A[l&15][8*(l>>4)+j], b[j] = B[8*(l>>4)+j][l&15]; c[r] = C[(l>>4)*4 + r][l&15].
+__device__ __forceinline__ f32x4 mfma16h(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 }  // namespace m3

@@ -87,7 +87,8 @@ struct m3_engine {
 
 namespace {
 
-bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const float** out) {
+// dtype: what the engine will read the tensor as (GEMM weights follow cfg.weight_dtype, everything else is fp32)
+bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const float** out, int dtype = M3_F32) {
   auto it = e->table.find(name);
   if (it == e->table.end()) {
     set_error("engine: weight '%s' missing from the plan", name.c_str());
@@ -98,12 +99,19 @@ bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const fl
               (long long)numel);
     return false;
   }
+  if (it->second.dtype != dtype) {
+    set_error("engine: weight '%s' has dtype %d, the engine (weight_dtype=%d) expects %d", name.c_str(),
+              (int)it->second.dtype, (int)e->cfg.weight_dtype, dtype);
+    return false;
+  }
   *out = (const float*)it->second.data;
   return true;
 }
 
 #define GET(dst, name, numel) \
-  if (!lookup(e, (name), (numel), &(dst))) return false
+  do { if (!lookup(e, (name), (numel), &(dst))) return false; } while (0)
+#define GETW(dst, name, numel) \
+  do { if (!lookup(e, (name), (numel), &(dst), e->cfg.weight_dtype)) return false; } while (0)
 
 bool load_norm(const m3_engine* e, const std::string& p, int d, Norm* n) {
   GET(n->g, p + "weight", d);
@@ -111,13 +119,18 @@ bool load_norm(const m3_engine* e, const std::string& p, int d, Norm* n) {
   return true;
 }
 bool load_lin(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n_in, bool bias, Lin* l) {
-  GET(l->w, p + "weight", n_out * n_in);
+  GETW(l->w, p + "weight", n_out * n_in);
   if (bias) GET(l->b, p + "bias", n_out);
   return true;
 }
 // Linear with a LayerNorm folded in (plan.py fold_layernorm): weight = W*gamma, bias = b + W.beta, wsum = rowsum(W*gamma)
-bool load_lin_ln(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n_in, bool wbeta, Lin* l) {
-  GET(l->w, p + "ln.weight", n_out * n_in);
+bool load_lin_ln(const m3_engine* e, const std::string& p, int64_t n_out, int64_t n_in, bool wbeta, Lin* l,
+                 bool fp32_only = false) {
+  if (fp32_only) {
+    GET(l->w, p + "ln.weight", n_out * n_in);
+  } else {
+    GETW(l->w, p + "ln.weight", n_out * n_in);
+  }
   GET(l->b, p + "ln.bias", n_out);
   GET(l->wsum, p + "ln.wsum", n_out);
   if (wbeta) GET(l->wbeta, p + "ln.wbeta", n_out);
@@ -150,11 +163,11 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
     const int64_t Etot = (int64_t)c.num_experts * world;
     GET(b->router.w, p + "feed_forward.router_weights_t", Etot * (D + De));
     if (c.router_with_bias) GET(b->router.b, p + "feed_forward.router_bias", Etot);
-    if (c.fuse_route && !load_lin_ln(e, p + "feed_forward.router_x.", Etot, D, false, &b->router_x)) return false;
+    if (c.fuse_route && !load_lin_ln(e, p + "feed_forward.router_x.", Etot, D, false, &b->router_x, true)) return false;
     const int64_t E = c.num_experts;
-    GET(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
+    GETW(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
     GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
-    GET(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
+    GETW(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
     GET(b->eb2, p + "feed_forward.experts.w_2.bias", E * D);
   }
   return true;
@@ -164,11 +177,12 @@ bool load_sub(const m3_engine* e, const std::string& p, int D, int idim, SubW* s
   const int F2 = ((idim - 1) / 2 - 1) / 2;
   GET(s->c1w, p + "conv.0.weight_9c", 9 * (int64_t)D);
   GET(s->c1b, p + "conv.0.bias", D);
-  GET(s->c2w, p + "conv.2.weight_ohwi", 9 * (int64_t)D * D);
+  GETW(s->c2w, p + "conv.2.weight_ohwi", 9 * (int64_t)D * D);
   GET(s->c2b, p + "conv.2.bias", D);
   return load_lin(e, p + "out.0.", D, (int64_t)D * F2, true, &s->out);
 }
 #undef GET
+#undef GETW
 
 inline int sub_len(int t) { return ((t - 3) / 2 + 1 - 3) / 2 + 1; }
 
@@ -234,7 +248,9 @@ static void add_stage(m3_engine* e, const std::string& name, int kernels, std::f
   e->n_kernels += kernels;
 }
 
-static void add_gemm(m3_engine* e, const std::string& name, const GemmParams& p) {
+// fp32_weights: the router GEMMs keep fp32 weights in every mode (a flipped top-1 is a discrete error)
+static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool fp32_weights = false) {
+  p.w_bf16 = (!fp32_weights && e->cfg.weight_dtype == M3_BF16) ? 1 : 0;
   add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); });
 }
 
@@ -360,7 +376,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // LayerNorm(norm_ff) rides in the router GEMM: applied to the x half of cat([embed, x]) and written
     // out once as xn, the expert FFN's input
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
-    add_gemm(e, pfx + "moe_router", r);
+    add_gemm(e, pfx + "moe_router", r, true);
     // "moe_local.*" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
     if (world == 1 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch
@@ -375,7 +391,9 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
       });
     }
+    const bool e16 = c.weight_dtype == M3_BF16;
     add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+      if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     });
     }
@@ -419,6 +437,12 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   if (c.attention_dim % 16 || c.embed_dim % 16 || c.hidden_units % 64 || c.embed_linear_units % 16)
     return fail("engine_create: dims must be multiples of 16 (hidden_units of 64)");
   if (c.embed_dim != c.attention_dim) return fail("engine_create: embed_dim != attention_dim is not supported");
+  if (c.weight_dtype != M3_F32 && c.weight_dtype != M3_BF16) return fail("engine_create: weight_dtype must be f32 or bf16");
+  if (c.weight_dtype == M3_BF16) {
+    if (c.fuse_route) return fail("engine_create: fuse_route is fp32-only");
+    if (c.attention_dim % 32 || c.hidden_units % 64 || c.embed_linear_units % 32)
+      return fail("engine_create: bf16 weights need dims that are multiples of 32");
+  }
   e->names.reserve(n_entries);
   for (int i = 0; i < n_entries; ++i) {
     if (!table[i].name || !table[i].data) return fail("engine_create: null weight entry");
@@ -452,7 +476,7 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
     e->pe = (const float*)it->second.data;
     e->pe_rows = it->second.numel / D;
   }
-  if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all)) return fail(nullptr);
+  if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all, c.weight_dtype)) return fail(nullptr);
   if (c.fuse_route && !lookup(e, "router_e_all.weight", (int64_t)c.num_blocks * c.num_experts * De, &e->router_e_all))
     return fail(nullptr);
   e->eblocks.resize(c.embed_blocks);
@@ -488,6 +512,8 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   M3_REQUIRE(Tp < e->pe_rows, "engine_prepare: T'=%d exceeds the positional table (%lld rows)", Tp,
              (long long)e->pe_rows);  // rel_positional_encoding_plugin.cpp:139-142
   if (int rc = init_expert_ffn_kernels()) return rc;
+  if (int rc = init_expert_ffn_bf16_kernels()) return rc;
+  if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   const Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   e->B = B; e->T = T; e->Tp = Tp; e->S = B * Tp;
@@ -507,6 +533,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams pp;
     pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
     if (c.fold_pos_proj) {
+      pp.w_bf16 = c.weight_dtype == M3_BF16;
       if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
       M3_CHECK_HIP(hipStreamSynchronize(nullptr));
     } else {
@@ -529,7 +556,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams g;
     g.A = pl.emb; g.lda = De; g.W = e->router_e_all; g.Y = pl.eall; g.ldy = c.num_blocks * c.num_experts;
     g.M = S; g.N = c.num_blocks * c.num_experts; g.K = De;
-    add_gemm(e, "router_e_all", g);
+    add_gemm(e, "router_e_all", g, true);
   }
   // ---- main MoE encoder (conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) ----
   build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);

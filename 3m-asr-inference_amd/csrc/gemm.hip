@@ -360,6 +360,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
 }
 
 int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
+  if (pin.w_bf16) return launch_gemm_bf16w(pin, stream);
   GemmParams p = pin;
   M3_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   M3_REQUIRE((p.K & 15) == 0, "gemm: K=%d must be a multiple of 16", p.K);

@@ -12,7 +12,8 @@ struct GemmParams {
   // operands: Y[M,Nout] = epi( pro(A)[M,K] . W[N,K]^T )
   const float* A = nullptr; int lda = 0;
   const float* A2 = nullptr; int lda2 = 0; int K1 = 0;   // CONCAT2: k<K1 from A, else A2[k-K1]
-  const float* W = nullptr;                               // [N][K] row-major
+  const float* W = nullptr;                               // [N][K] row-major (fp32, or bf16 when w_bf16)
+  int w_bf16 = 0;                                         // W holds bf16: operands rounded at the MFMA input, fp32 accumulate
   const float* bias = nullptr;                            // [N] or null
   float* Y = nullptr; int ldy = 0;
   int M = 0, N = 0, K = 0;
@@ -34,7 +35,9 @@ struct GemmParams {
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
-int launch_gemm_f32(const GemmParams& p, hipStream_t stream);
+int launch_gemm_f32(const GemmParams& p, hipStream_t stream);   // dispatches to launch_gemm_bf16w when p.w_bf16
+int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
+int init_gemm_bf16_tiled_kernels();   // once, outside graph capture (dynamic-LDS opt-in of the tiled kernels)
 
 // ---- MoE indexing / scatter / gather (moe_index.hip) ----
 int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist,
@@ -58,6 +61,11 @@ int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                           int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream);
+// bf16 weights (w1 [E][F][D], w2 as above), fp32 rows in / fp32 slab out (moe_expert_bf16.hip)
+int init_expert_ffn_bf16_kernels();
+int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
+                            int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* slab,
+                            hipStream_t stream);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,

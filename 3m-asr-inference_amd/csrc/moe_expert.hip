@@ -68,7 +68,8 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
   const int g2 = ((nsub + NWV - 1) / NWV + SPG - 1) / SPG;   // same for every wave (the barrier sits inside the loop)
   const int total = g1 + g2;
 
-  for (int r0 = row_lo; r0 < row_hi; r0 += 16 * MT) {
+  // an expert's row tiles are spread over blockIdx.z (long batches, unbalanced routing: no serial tile loop)
+  for (int r0 = row_lo + 16 * MT * blockIdx.z; r0 < row_hi; r0 += 16 * MT * gridDim.z) {
     const int nrows = min(16 * MT, row_hi - r0);
     float* slab_base = slab + ((size_t)slice * S + r0) * D;
 
@@ -245,7 +246,8 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
   const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(float);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn: LDS tile of %zu bytes does not fit", lds_bytes);
-  dim3 grid(F / kExpertSlice, E);
+  int zt = cdiv(S, 16 * mt);
+  dim3 grid(F / kExpertSlice, E, zt < 8 ? zt : 8);
   const int w2_row_stride = w2_sliced ? kExpertSlice : F;
   const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
   if (int rc = init_expert_ffn_kernels()) return rc;

@@ -34,7 +34,7 @@ class LinearDesc(C.Structure):  # m3_linear_desc
                 ("ln_wsum", C.c_void_p), ("ln_wbeta", C.c_void_p),
                 ("len", C.c_void_p), ("rows_per_batch", C.c_int32), ("mask_in", C.c_int32), ("mask_out", C.c_int32),
                 ("act", C.c_int32), ("alpha", C.c_float),
-                ("resid", C.c_void_p), ("ldr", C.c_int32)]
+                ("resid", C.c_void_p), ("ldr", C.c_int32), ("weight_dtype", C.c_int32)]
 
 
 class EngineConfig(C.Structure):  # m3_engine_config
@@ -42,11 +42,12 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "input_dim", "output_dim", "attention_dim", "attention_heads", "num_blocks",
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
-        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route")]
+        "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
+        "weight_dtype")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
-    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64), ("dtype", C.c_int32)]
 
 
 FIELD_FLOAT32, FIELD_INT32 = 1, 5
@@ -83,6 +84,8 @@ SIGNATURES = {
     "m3_moe_expert_workspace_size": (_sz, [_i, _i, _i, _i]),
     "m3_moe_expert_ffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                _vp, _sz, _vp]),
+    "m3_moe_expert_ffn_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
+                                    _vp, _sz, _vp]),
     "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "m3_linear": (_i, [_P(LinearDesc), _vp]),

@@ -33,6 +33,9 @@ class EncoderConfig:
     ep_world_size: int = 1
     ep_rank: int = 0
     max_len: int = 5000            # positional_encoding.py:31
+    # storage of the GEMM weights: "f32" (exact fp32 MFMA) or "bf16" (bf16 MFMA, fp32 accumulate; activations stay
+    # fp32) = the reference's --fp16 / plugin_data_type 1 (builder.py:160, builder_helper.py:47-57)
+    weight_dtype: str = "f32"
     log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
 
     @property

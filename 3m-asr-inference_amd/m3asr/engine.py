@@ -15,6 +15,9 @@ from .config import EncoderConfig, subsampled_len
 from .plan import pack_weights
 
 
+_TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32}
+
+
 def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
@@ -29,13 +32,14 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
     ec.fold_pos_proj, ec.debug_taps, ec.fuse_route = int(fold_pos_proj), int(debug_taps), int(fuse_route)
     ec.log_softmax_out = int(cfg.log_softmax_out)
+    ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16}[cfg.weight_dtype]
     return ec
 
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False,
                  fuse_route=False):
-        """packed: output of plan.pack_weights / plan.load_plan (CPU fp32 tensors), or the ``weights`` dict of another
+        """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine)."""
         self.lib = _lib.load()
@@ -52,6 +56,7 @@ class Engine:
             table[i].name = self._keep[i]
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
+            table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
         ec = _engine_config(cfg, fold_pos_proj, debug_taps, fuse_route and cfg.ep_world_size <= 1)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
@@ -74,7 +79,7 @@ class Engine:
             self.lib.m3_engine_destroy(h)
 
     def weight_bytes(self):
-        return sum(v.numel() * 4 for v in self.weights.values())
+        return sum(v.numel() * v.element_size() for v in self.weights.values())
 
     def output_shape(self, B, T):
         return (B, subsampled_len(T), self.cfg.output_dim)

@@ -21,6 +21,7 @@ File format (``save_plan`` / ``load_plan``): 8-byte magic, u64 header length, JS
 {config, tensors: {name: [offset, shape]}}, then raw little-endian fp32 data (256-B aligned).
 """
 import json
+import re
 import math
 import struct
 from collections import OrderedDict
@@ -161,7 +162,7 @@ def pack_weights(state_dict, cfg: EncoderConfig):
     out["pos_all.weight"] = torch.cat(
         [sd["embed.blocks.%d.self_attn.linear_pos.weight" % i] for i in range(cfg.embed_blocks)] +
         [sd["blocks.%d.self_attn.linear_pos.weight" % i] for i in range(cfg.num_blocks)], 0)
-    return OrderedDict((k, v.contiguous()) for k, v in out.items())
+    return cast_gemm_weights(OrderedDict((k, v.contiguous()) for k, v in out.items()), cfg)
 
 
 def read_cmvn_stats(path):
@@ -197,11 +198,48 @@ def add_front_back_end(packed, cfg, cmvn=None, output_bias=None):
     return packed
 
 
+# GEMM weights that follow cfg.weight_dtype (csrc/engine.hip GETW); everything else -- router, norms, biases,
+# conv1, depthwise conv, positional table -- stays fp32 in every mode.
+_GEMM_WEIGHT = re.compile(
+    r"((feed_forward_macaron|feed_forward)\.w_1|self_attn\.qkv|pointwise_conv1|^out_linear)\.ln\.weight$"
+    r"|((feed_forward_macaron|feed_forward)\.w_2|self_attn\.linear_out|pointwise_conv2|subsampling\.out\.0)\.weight$"
+    r"|experts\.w_1\.weight$|experts\.w_2\.weight_sliced$|conv\.2\.weight_ohwi$|^pos_all\.weight$")
+
+
+def is_gemm_weight(name):
+    return _GEMM_WEIGHT.search(name) is not None
+
+
+def cast_gemm_weights(packed, cfg: EncoderConfig):
+    """Store the GEMM weights in cfg.weight_dtype ("f32" = no-op, "bf16" = round to nearest even).  The reference
+    wires --fp16 / plugin_data_type = 1 (builder.py:160, builder_helper.py:47-57,109-123) without finishing it; bf16 is
+    the 16-bit type on CDNA4.  The folded LayerNorm's column sums are recomputed from the ROUNDED weights, so that
+    y = rstd * (a . W'^T - mean * wsum) stays an exact identity for the weights the kernel really multiplies by."""
+    if cfg.weight_dtype == "f32":
+        return packed
+    assert cfg.weight_dtype == "bf16", cfg.weight_dtype
+    out = OrderedDict()
+    for k, v in packed.items():
+        if is_gemm_weight(k) and v.dtype == torch.float32:
+            out[k] = v.to(torch.bfloat16).contiguous()
+        else:
+            out[k] = v
+    for k in list(out):
+        if k.endswith(".ln.weight") and out[k].dtype == torch.bfloat16:
+            out[k[:-len("weight")] + "wsum"] = out[k].double().sum(1).float()
+    return out
+
+
+_DTYPES = {"f32": (torch.float32, "<f4", 4), "bf16": (torch.bfloat16, "<u2", 2), "i32": (torch.int32, "<i4", 4)}
+_DTYPE_NAME = {torch.float32: "f32", torch.bfloat16: "bf16", torch.int32: "i32"}
+
+
 def save_plan(path, cfg: EncoderConfig, packed, extra=None):
     index, off = {}, 0
     for k, v in packed.items():
-        index[k] = [off, list(v.shape)]
-        off += (v.numel() * 4 + 255) // 256 * 256
+        name = _DTYPE_NAME[v.dtype]
+        index[k] = [off, list(v.shape)] + ([name] if name != "f32" else [])
+        off += (v.numel() * _DTYPES[name][2] + 255) // 256 * 256
     header = json.dumps({"config": json.loads(cfg.to_json()), "tensors": index, "extra": extra or {}}).encode()
     with open(path, "wb") as f:
         f.write(MAGIC)
@@ -210,13 +248,16 @@ def save_plan(path, cfg: EncoderConfig, packed, extra=None):
         pad = (-(16 + len(header))) % 256
         f.write(b"\0" * pad)
         for k, v in packed.items():
-            b = v.contiguous().numpy().astype("<f4", copy=False).tobytes()
+            if v.dtype == torch.bfloat16:
+                b = v.contiguous().view(torch.int16).numpy().astype("<i2", copy=False).tobytes()
+            else:
+                b = v.contiguous().numpy().astype(_DTYPES[_DTYPE_NAME[v.dtype]][1], copy=False).tobytes()
             f.write(b)
             f.write(b"\0" * ((-len(b)) % 256))
 
 
 def load_plan(path):
-    """-> (EncoderConfig, OrderedDict name -> CPU fp32 tensor (memory-mapped), extra dict)"""
+    """-> (EncoderConfig, OrderedDict name -> CPU tensor (fp32; bf16 for the GEMM weights of a bf16 plan), extra dict)"""
     with open(path, "rb") as f:
         if f.read(8) != MAGIC:
             raise ValueError("%s is not an m3asr plan" % path)
@@ -226,8 +267,14 @@ def load_plan(path):
     base += (-base) % 256
     mm = np.memmap(path, dtype=np.uint8, mode="r")
     packed = OrderedDict()
-    for k, (off, shape) in header["tensors"].items():
+    for k, ent in header["tensors"].items():
+        off, shape = ent[0], ent[1]
+        tdt, ndt, _ = _DTYPES[ent[2] if len(ent) > 2 else "f32"]
         n = int(np.prod(shape)) if shape else 1
-        arr = np.frombuffer(mm, dtype="<f4", count=n, offset=base + off).reshape(shape)
-        packed[k] = torch.from_numpy(np.array(arr, copy=True))
+        if tdt == torch.bfloat16:
+            arr = np.frombuffer(mm, dtype="<i2", count=n, offset=base + off).reshape(shape)
+            packed[k] = torch.from_numpy(np.array(arr, copy=True)).view(torch.bfloat16)
+        else:
+            arr = np.frombuffer(mm, dtype=ndt, count=n, offset=base + off).reshape(shape)
+            packed[k] = torch.from_numpy(np.array(arr, copy=True))
     return EncoderConfig(**header["config"]), packed, header.get("extra", {})

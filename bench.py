@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--fuse-route", action="store_true",
                     help="router + SoftmaxTopK + ScatterMapping as one single-workgroup launch per layer (275 instead of "
                          "292 kernels; measured 2-3 %% slower than the staged path, so off by default)")
+    ap.add_argument("--weight-dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage of the GEMM weights (bf16 = BASELINE.json configs[2]; the headline metric is f32)")
+    ap.add_argument("--varlen", default="", help="LO-HI: utterance lengths drawn from U[LO,HI] frames (configs[2]: 50-500)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
     return ap.parse_args()
 
@@ -91,8 +94,11 @@ def balance_router(eng, cpu_weights):
         idx = names.index("blocks.%d.moe_router" % li)
         eng.run_stages(first, idx + 1)
         eng.stream.synchronize()
-        mu = torch.cat([eng.buffer("embed").view(-1, eng.cfg.embed_dim).mean(0),
-                        eng.buffer("xn").view(-1, eng.cfg.attention_dim).mean(0)])
+        lens = eng.buffer("lens", torch.int32)
+        Bb = lens.numel()
+        emb, xn = eng.buffer("embed").view(Bb, -1, eng.cfg.embed_dim), eng.buffer("xn").view(Bb, -1, eng.cfg.attention_dim)
+        valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
+        mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
         w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
         w -= torch.outer(w @ mu, mu) / (mu @ mu)
         eng.run_stages(idx, idx + 1)                                              # logits with the new weights
@@ -120,15 +126,23 @@ def main():
     from m3asr.weights import make_weights
     from m3asr.engine import Engine
 
-    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts)
+    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts, weight_dtype=args.weight_dtype)
     weights = make_weights(cfg, seed=0)
 
     # synthetic input: U[0,1) features as data/generate_trtexec_inputs.py:7 of the reference; each rank its own utterance
     rng = np.random.default_rng(1234 + rank)
     B, T = args.batch, args.frames
+    if args.varlen:
+        lo, hi = (int(v) for v in args.varlen.split("-"))
+        lengths = rng.integers(lo, hi + 1, B)
+        lengths[0] = hi                      # the padded length is always HI
+        T = int(lengths.max())
+    else:
+        lengths = np.full(B, T)
+    n_frames = int(lengths.sum())            # real (unpadded) input frames per step per rank
     feat_cpu = torch.from_numpy(rng.random((B, T, cfg.input_dim), dtype=np.float32))
     feat = feat_cpu.to(dev)
-    feat_len = torch.full((1, B), T, dtype=torch.int32, device=dev)
+    feat_len = torch.from_numpy(lengths.astype(np.int32)).view(1, B).to(dev)
     # the staged-route engine exposes xn / the router stage, which the synthetic-router calibration needs
     eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False)
     if args.routing == "balanced":
@@ -179,7 +193,7 @@ def main():
         eng.forward(use_graph=use_graph)
     eng.stream.synchronize()
     latency_ms = (time.perf_counter() - t1) / 50 * 1e3
-    frames_per_step = world * B * T
+    frames_per_step = world * n_frames
     value = frames_per_step / (dt / args.steps)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the engine's stream ----
@@ -200,7 +214,8 @@ def main():
         for li in range(cfg.num_blocks):
             g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
             touched.append(len(np.unique(g[g >= 0])))
-        bytes_alg = np.array([t_ * (2 * D * F + F + D) * 4 + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
+        wsz = 2 if cfg.weight_dtype == "bf16" else 4        # expert weights in weight_dtype, biases and rows fp32
+        bytes_alg = np.array([t_ * (2 * D * F * wsz + (F + D) * 4) + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
         # duration of the roofline kernel IN SITU: whole forwards are enqueued stage by stage on the engine stream
         # (the GPU stays the bottleneck: ~3.5 us host cost per launch vs ~8 us per kernel) with HIP events only around
         # each layer's expert launch, so the kernel sees the cache state of a real forward -- repeated in isolation its
@@ -225,12 +240,13 @@ def main():
         achieved = float((bytes_alg / dur).mean() / 1e9)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
-        if os.path.exists(pmc):          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same command)
+        kname = "expert_ffn_bf16w_kernel" if cfg.weight_dtype == "bf16" else "expert_ffn_f32_kernel"
+        if os.path.exists(pmc) and cfg.weight_dtype == "f32" and B == 1 and T == 206:          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same command)
             try:
                 traffic = json.load(open(pmc))["kernels"]["void m3::expert_ffn_f32_kernel<1>"]["traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roofline = {"kernel": "expert_ffn_f32_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "avg_launch_us": round(float(dur.mean() * 1e6), 2),
                     "alg_bytes_per_launch": int(bytes_alg.mean()),
@@ -240,7 +256,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.encoder_ref import encoder_forward
-        fl_cpu = torch.full((B,), T, dtype=torch.int32)
+        fl_cpu = torch.from_numpy(lengths.astype(np.int32))
         cores = args.cpu_threads if args.cpu_threads > 0 else min(32, os.cpu_count() or 1)
         torch.set_num_threads(cores)
         times = []
@@ -251,21 +267,30 @@ def main():
             ref_logits = encoder_forward(weights, cfg, feat_cpu, fl_cpu)
             times.append(time.perf_counter() - c0)
         med = float(np.median(times))
-        cpu = {"value": round(B * T / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": "%d full forwards of the same 1x%d-frame %dL/%de workload (median %.1f ms), torch %s fp32" % (
-                   len(times), T, cfg.num_blocks, cfg.num_experts, med * 1e3, torch.__version__)}
+        cpu = {"value": round(n_frames / med, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d full forwards of the same %dx%d-frame %dL/%de workload (median %.1f ms), torch %s fp32" % (
+                   len(times), B, T, cfg.num_blocks, cfg.num_experts, med * 1e3, torch.__version__)}
         # the checker: GPU logits of the timed workload vs the oracle's
         got = eng._bound[2].cpu()
-        rel = float(((got - ref_logits).abs() / (ref_logits.abs() + 2e-1)).max())
+        vmask = (torch.arange(got.shape[1]).view(1, -1) < torch.tensor([subsampled_len(int(l)) for l in lengths]).view(-1, 1))
+        rel = float(((got - ref_logits).abs() / (ref_logits.abs() + 2e-1))[vmask].max())
         cpu["gpu_vs_oracle_max_rel"] = round(rel, 6)
 
     if rank == 0:
-        out = {"metric": "encoder frames/sec, 18Lx32e Conformer-MoE, 206-frame utterance",
+        metric = "encoder frames/sec, 18Lx32e Conformer-MoE, 206-frame utterance"
+        if args.varlen or B != 1 or T != 206:
+            metric = "encoder frames/sec, %dLx%de Conformer-MoE, batch=%d %s" % (
+                cfg.num_blocks, cfg.num_experts, B, ("var-len %s frames" % args.varlen) if args.varlen else "%d-frame utterances" % T)
+        out = {"metric": metric,
                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "18-layer 32-expert fp32, batch=%dx%d frames per GPU, all experts local "
-                                      "(BASELINE.json configs[1])" % (B, T),
+               "dtype": cfg.weight_dtype, "data": "synthetic",
+               "config": {"workload": "%d-layer %d-expert %s, batch=%dx%d frames per GPU%s, all experts local "
+                                      "(BASELINE.json configs[%d])" % (
+                                          cfg.num_blocks, cfg.num_experts, "fp32" if cfg.weight_dtype == "f32" else
+                                          "bf16 weights / bf16 MFMA / fp32 accumulate + activations", B, T,
+                                          (" (lengths U[%s], %d real frames)" % (args.varlen, n_frames)) if args.varlen else "",
+                                          1 if cfg.weight_dtype == "f32" else 2),
                           "layers": cfg.num_blocks, "experts": cfg.num_experts, "frames": T, "batch_per_gpu": B,
                           "parallelism": "replicas x%d" % world, "streams_per_gpu": len(ctxs),
                           "latency_ms_one_stream": round(latency_ms, 4), "hip_graph": use_graph,

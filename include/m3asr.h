@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 1
+#define M3ASR_ABI_VERSION 2
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -115,6 +115,14 @@ int m3_moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, 
                       const float* gate_value, const float* resid, float alpha, const float* ln_gamma,
                       const float* ln_beta, float ln_eps, float* y, void* workspace, size_t workspace_bytes,
                       m3_stream stream);
+/* The same with bf16 expert weights (w1 / w2 point at bf16 [E][F][D] / [E][D][F]; biases, rows, epilogue fp32):
+ * the half-precision mode the reference declares (`data_type` plugin field, fmoe_expert_plugin.cpp:331-354) but
+ * asserts on (:264-266).  Rows and H are rounded to bf16 at the MFMA inputs, accumulation is fp32. */
+int m3_moe_expert_ffn_bf16(const float* x, const int32_t* gate_idx, const void* w1, const float* b1,
+                           const void* w2, const float* b2, int S, int num_expert, int idim, int hidden_units,
+                           const float* gate_value, const float* resid, float alpha, const float* ln_gamma,
+                           const float* ln_beta, float ln_eps, float* y, void* workspace, size_t workspace_bytes,
+                           m3_stream stream);
 /* The tail of the MoE layer on rows that are already in scattered (expert-sorted) order, e.g. rows that came back
  * from the expert-parallel all-to-all:  out[s] = LayerNorm( resid[s] + alpha * gate_value[s] * rows[mapping[s]] )
  * (rows with mapping < 0 contribute 0; gate_value / resid / ln_* may be NULL).  = local_gather
@@ -138,7 +146,8 @@ int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_pe
 typedef struct m3_linear_desc {
   const float* a; int32_t lda;
   const float* a2; int32_t lda2; int32_t k1;
-  const float* w; const float* bias;
+  const void* w;   /* [N][K] row-major; fp32, or bf16 when weight_dtype = M3_BF16 */
+  const float* bias;
   float* y; int32_t ldy;
   int32_t M, N, K;
   const float* ln_gamma; const float* ln_beta; float ln_eps;
@@ -148,6 +157,10 @@ typedef struct m3_linear_desc {
   const int32_t* len; int32_t rows_per_batch; int32_t mask_in; int32_t mask_out;
   int32_t act; float alpha;
   const float* resid; int32_t ldr;
+  /* M3_F32 (exact fp32 MFMA) or M3_BF16: weights stored bf16, A rounded to bf16 at the MFMA input,
+   * fp32 accumulate and fp32 epilogue (the reference's plugin_data_type = 1, builder_helper.py:47-57; bf16
+   * replaces fp16 on CDNA4).  bf16 supports plain A (no a2) and the folded LayerNorm only; K % 32 == 0. */
+  int32_t weight_dtype;
 } m3_linear_desc;
 int m3_linear(const m3_linear_desc* desc, m3_stream stream);
 
@@ -224,12 +237,15 @@ typedef struct m3_engine_config {
   int32_t debug_taps;            /* 1 = keep every block's output (the reference's DumpTensor taps) */
   int32_t log_softmax_out;       /* 1 = output log_softmax(logits) (+ "output_bias" weight entry if present, e.g. -log prior) */
   int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank) */
+  int32_t weight_dtype;          /* M3_F32 / M3_BF16: storage of the GEMM weights (linear / point-wise conv /
+                                  * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32 */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {
   const char* name; /* packed tensor name, see m3asr/plan.py */
   const void* data; /* device pointer */
   int64_t numel;
+  int32_t dtype;    /* enum m3_dtype; checked against what the engine expects for that tensor */
 } m3_weight_entry;
 
 m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entry* table, int n_entries);

@@ -189,7 +189,7 @@ def fmoe_expert(x, gate_idx, w1, b1, w2, b2):
     return y.view(B, T, D), mapping, acc
 
 
-def moe_ffn(x, embed, lens, w, p, cfg, taps=None, tag=""):
+def moe_ffn(x, embed, lens, w, p, cfg, taps=None, tag="", route_override=None):
     """LocalFmoeCatEmbedFeedForward.forward (layer/positionwise_feed_forward.py:209-265):
     router_in = cat([embed, x]); logits = router_in @ router_weights (+bias); top-1 softmax gate;
     expert FFN; output * gate_value unless keep_expert_output."""
@@ -198,6 +198,13 @@ def moe_ffn(x, embed, lens, w, p, cfg, taps=None, tag=""):
     if (p + "router_bias") in w:
         logits = logits + w[p + "router_bias"]
     gate_value, gate_idx = softmax_topk(logits, lens)
+    if route_override is not None and (tag + "gate_idx") in route_override:
+        # teacher-forced routing (low-precision tests): take the expert choice from the run under test and the softmax
+        # probability of THAT expert, so numeric error is measured without the discrete effect of a flipped arg-max
+        gate_idx = route_override[tag + "gate_idx"].view(gate_idx.shape).to(torch.int32)
+        prob = torch.softmax(logits, dim=-1)
+        gate_value = torch.gather(prob, -1, gate_idx.clamp(min=0).long())
+        gate_value = torch.where(gate_idx >= 0, gate_value, torch.zeros_like(gate_value))
     y, mapping, acc = fmoe_expert(x, gate_idx, w[p + "experts.w_1.weight"], w[p + "experts.w_1.bias"],
                                   w[p + "experts.w_2.weight"], w[p + "experts.w_2.bias"])
     if taps is not None:
@@ -212,7 +219,7 @@ def moe_ffn(x, embed, lens, w, p, cfg, taps=None, tag=""):
     return y
 
 
-def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe, taps=None, tag=""):
+def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe, taps=None, tag="", route_override=None):
     """FmoeConformerLayer.forward (layer/fmoe_transformer.py:72-170) when moe=True,
     ConformerEncoderLayer.forward (layer/transformer.py:179-275) otherwise; ff_scale = 0.5,
     all block LayerNorms eps=1e-12 (fmoe_transformer.py:54-65)."""
@@ -228,7 +235,7 @@ def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe
         taps[tag + "after_conv"] = x
     xn = layer_norm(x, w, p + "norm_ff.", eps)
     if moe:
-        y = moe_ffn(xn, embed, lens, w, p + "feed_forward.", cfg, taps, tag)
+        y = moe_ffn(xn, embed, lens, w, p + "feed_forward.", cfg, taps, tag, route_override)
     else:
         y = ffn(xn, w, p + "feed_forward.")
     x = x + 0.5 * y
@@ -238,7 +245,7 @@ def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe
     return x
 
 
-def encoder_forward(w, cfg, feat, feat_len, taps=None):
+def encoder_forward(w, cfg, feat, feat_len, taps=None, route_override=None):
     """Net.forward (model/conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) with the
     embed encoder of model/conformer_embed_domain_acc.py:149-181.
     feat (B,T,idim) f32, feat_len (1,B) or (B,) int -> logits (B,T',V)."""
@@ -262,6 +269,6 @@ def encoder_forward(w, cfg, feat, feat_len, taps=None):
         x, pos = rel_pos_enc(x)
         for i in range(cfg.num_blocks):
             x = conformer_block(x, embed, lens, pos, w, "blocks.%d." % i, cfg, cfg.attention_heads,
-                                cfg.cnn_module_kernel, cfg.cnn_module_norm, True, taps, "blocks.%d." % i)
+                                cfg.cnn_module_kernel, cfg.cnn_module_norm, True, taps, "blocks.%d." % i, route_override)
         x = layer_norm(x, w, "after_norm.", 1e-12)
         return F.linear(x, w["out_linear.weight"], w["out_linear.bias"])
