@@ -392,13 +392,16 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       });
     }
     const bool e16 = c.weight_dtype == M3_BF16;
-    add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+    add_stage(e, pfx + "moe_local.expert", (e16 && expert_ffn_bf16_tiled(S, E, D, F)) ? 2 : 1, [=](hipStream_t s) {
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     });
     }
+    const bool e16c = c.weight_dtype == M3_BF16 && !fused_route;
+    const float* erows = e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : mw.slab;
+    const int eslices = e16c ? expert_ffn_bf16_slices(S, E, D, F) : F / kExpertSlice;
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
-      return launch_moe_combine(mw.slab, F / kExpertSlice, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
+      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
     });
     const std::string b = pfx.substr(0, pfx.size() - 1);
     e->buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};

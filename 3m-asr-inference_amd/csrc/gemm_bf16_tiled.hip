@@ -31,12 +31,18 @@ constexpr int tiled_lds_bytes(int BM, int BN, int BK) {
 }
 }
 
-template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN>
+// GRP = 0: dense GEMM.  GRP = 1 / 2: the two GEMMs of the grouped expert FFN for long batches (moe_expert_tiled):
+//   row tiles are cut per expert from acc_hist (p.grp_acc), W / bias are that expert's;
+//   1: A rows are gathered through pos (fused local_scatter), fp32 -> H = SiLU(. + b1) written as bf16 in sorted order;
+//   2: A = H (bf16, no conversion while staging), W2 in the plan's slice-major layout or [D][F], fp32 rows out.
+template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN, int GRP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmParams p) {
+  static_assert(GRP == 0 || (!GLU && !CONV && !LN), "grouped form is a plain GEMM");
   constexpr int T_LD = TBK + 8;                     // bf16 elements per LDS row (144 / 272 B: conflict-free 16-B reads)
   constexpr int C_LD = TBN + 4;                     // fp32 elements per row of the epilogue image
   constexpr int MT = TBM / 32, NT = TBN / 32;       // 16x16 MFMA tiles per wave (wave tile = TBM/2 x TBN/2)
-  constexpr int CA = TBK / 4, RA = 256 / CA, JA = TBM / RA;   // A staging: float4 chunks per row, rows per pass, passes
+  constexpr bool A16 = GRP == 2;                    // A operand already bf16 (16-B chunks of 8 elements)
+  constexpr int CA = A16 ? TBK / 8 : TBK / 4, RA = 256 / CA, JA = TBM / RA;   // A staging: chunks per row, rows per pass, passes
   constexpr int CB = TBK / 8, RB = 256 / CB, JB = TBN / RB;   // W staging: 16-B chunks per row, rows per pass, passes
   extern __shared__ __attribute__((aligned(16))) unsigned char tiled_lds[];
   bf16_t* As = reinterpret_cast<bf16_t*>(tiled_lds);                // [2][TBM][T_LD]
@@ -49,8 +55,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   const int wm = wave >> 1, wn = wave & 1;
   const int Nout = GLU ? (p.N >> 1) : p.N;
   constexpr int OUTW = GLU ? TBN / 2 : TBN;         // output columns per workgroup
-  const int n_tile = blockIdx.x % p.n_tiles, m_tile = blockIdx.x / p.n_tiles;
-  const int m0 = m_tile * TBM, n0 = n_tile * OUTW;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own L2.  All column
+  // tiles of one row tile run on the SAME XCD, back to back, so an A tile (fp32, the dominant traffic) is fetched from
+  // HBM / Infinity Cache once instead of once per XCD; only W (small) is replicated over the L2s.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_tile = slot % p.n_tiles, m_tile = (slot / p.n_tiles) * 8 + xcd;
+  int m0 = m_tile * TBM, m_end = p.M, expert = 0;
+  if (GRP) {   // m_tile counts the row tiles of all experts in expert order: find its expert
+    if (p.grp_E <= 64) {
+      // one load per lane + a wave prefix sum instead of E dependent scalar loads (those were ~5 us of a ~15 us kernel)
+      const int lo = lane < p.grp_E ? p.grp_acc[lane] : 0, hi = lane < p.grp_E ? p.grp_acc[lane + 1] : 0;
+      const int nt_e = (hi - lo + TBM - 1) / TBM;
+      int incl = nt_e;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+      }
+      const unsigned long long owner = __ballot(m_tile < incl);   // lanes (experts) whose tile range ends after m_tile
+      if (owner == 0) return;                        // past the last tile (whole workgroup exits)
+      const int e = __ffsll((long long)owner) - 1;
+      expert = e;
+      const int t = m_tile - (__shfl(incl, e, 64) - __shfl(nt_e, e, 64));
+      m0 = __shfl(lo, e, 64) + t * TBM;
+      m_end = __shfl(hi, e, 64);
+    } else {
+      int t = m_tile, e = 0;
+      for (; e < p.grp_E; ++e) {
+        const int lo = p.grp_acc[e], hi = p.grp_acc[e + 1];
+        const int nt_e = (hi - lo + TBM - 1) / TBM;
+        if (t < nt_e) {
+          m0 = lo + t * TBM;
+          m_end = hi;
+          break;
+        }
+        t -= nt_e;
+      }
+      if (e == p.grp_E) return;
+      expert = e;
+    }
+  } else if (m_tile >= p.m_tiles) {
+    return;                                         // padding of the last group of 8 row tiles
+  }
+  const int n0 = n_tile * OUTW;
 
   // first W-tile row of accumulator tile nt of this wave; GLU: tile rows [0, TBN/2) value, [TBN/2, TBN) gate columns
   auto btile = [&](int nt) {
@@ -64,8 +111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   bool a_zero[JA];
 #pragma unroll
   for (int j = 0; j < JA; ++j) {
-    const int m = min(m0 + ar0 + RA * j, p.M - 1);
-    if (CONV) {
+    const int m = min(m0 + ar0 + RA * j, m_end - 1);
+    if (GRP == 1) {
+      aptr[j] = p.A + (size_t)p.grp_pos[m] * p.lda + 4 * ac;
+    } else if (GRP == 2) {
+      aptr[j] = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(p.A) + (size_t)m * p.lda + 8 * ac);
+    } else if (CONV) {
       const int f2 = m % p.conv_F2;
       const int t2 = (m / p.conv_F2) % p.conv_T2;
       const int b = m / (p.conv_F2 * p.conv_T2);
@@ -77,14 +128,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   }
   // W: thread t brings 16-B chunk (t % CB) of tile rows (t / CB) + RB j
   const int bc = tid % CB, br0 = tid / CB;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + (GRP ? (size_t)expert * p.N * p.K : 0);
   const bf16_t* bptr[JB];
+  int brow_n[JB];
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int tr = br0 + RB * j;
     const int n = GLU ? (tr / (TBN / 2)) * Nout + min(n0 + (tr % (TBN / 2)), Nout - 1) : min(n0 + tr, p.N - 1);
+    brow_n[j] = n;
     bptr[j] = W + (size_t)n * p.K + 8 * bc;
   }
+  // slice-major W (plan's expert w_2: [K/64][N][64]): the 8-element chunk kc of row n sits at ((kc>>3)*N + n)*64 + 8*(kc&7)
+  auto w_ptr = [&](int j, int s) -> const bf16_t* {
+    if (GRP == 2 && p.w_sliced) {
+      const int kc = s * CB + bc;
+      return W + ((size_t)(kc >> 3) * p.N + brow_n[j]) * 64 + 8 * (kc & 7);
+    }
+    return bptr[j] + s * TBK;
+  };
   auto a_offset = [&](int k) -> int {
     if (CONV) {
       const int seg = k / p.conv_C, c = k - seg * p.conv_C;
@@ -104,22 +165,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   for (int j = 0; j < JA; ++j) s1[j] = s2[j] = 0.f;
 
   const int nsteps = p.K / TBK;
-  f32x4 areg[JA];
+  f32x4 areg[JA];                                   // A16: the 16 bytes are 8 bf16, carried as they are
   bf16x8 breg[JB];
   auto load_tiles = [&](int s) {
-    const int ko = a_offset(s * TBK);
+    const int ko = A16 ? (s * TBK) / 2 : a_offset(s * TBK);       // in floats
 #pragma unroll
     for (int j = 0; j < JA; ++j) areg[j] = ldg4(aptr[j] + ko);
 #pragma unroll
-    for (int j = 0; j < JB; ++j) breg[j] = ldg8h(bptr[j] + s * TBK);
+    for (int j = 0; j < JB; ++j) breg[j] = ldg8h(w_ptr(j, s));
   };
   // `on` = 0 for the redundant store after the last k-step (the store stays unconditional, see the header)
   auto store_tiles = [&](int buf, float on) {
-    bf16_t* a_dst = As + buf * (TBM * T_LD) + ar0 * T_LD + 4 * ac;
+    bf16_t* a_dst = As + buf * (TBM * T_LD) + ar0 * T_LD + (A16 ? 8 : 4) * ac;
     bf16_t* b_dst = Bs + buf * (TBN * T_LD) + br0 * T_LD + 8 * bc;
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const f32x4 v = areg[j];
+      if (A16) {
+        *reinterpret_cast<f32x4*>(a_dst + RA * j * T_LD) = v;
+        continue;
+      }
       if (LN) {
         s1[j] += on * ((v[0] + v[1]) + (v[2] + v[3]));
         s2[j] += on * ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
@@ -191,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ne = min(n + e, Nout - 1);
-    bias0[e] = p.bias ? p.bias[ne] : 0.f;
+    bias0[e] = p.bias ? p.bias[(GRP ? (size_t)expert * p.N : 0) + ne] : 0.f;
     bias1[e] = (GLU && p.bias) ? p.bias[ne + Nout] : 0.f;
     wsum0[e] = LN ? p.ln_wsum[ne] : 0.f;
     wsum1[e] = (LN && GLU) ? p.ln_wsum[ne + Nout] : 0.f;
@@ -202,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   for (int it = 0; it < TBM / (4 * RPI); ++it) {
     const int row = (4 * it + wave) * RPI + lane / LPR;
     const int m = m0 + row;
-    if (m >= p.M || n >= Nout) continue;
+    if (m >= m_end || n >= Nout) continue;
     bool pad = false;
     if (p.mask_in || p.mask_out) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
     float mean = 0.f, rstd = 1.f;
@@ -246,7 +311,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       if (p.resid) t += res[e];
       y[e] = t;
     }
-    if (vec_ok) {
+    if (GRP == 1) {   // H in bf16 (N % 4 == 0 checked by the launcher)
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (bf16_t)y[e];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
+    } else if (vec_ok) {
       stg4(p.Y + (size_t)m * p.ldy + n, y);
     } else {
 #pragma unroll
@@ -263,12 +333,17 @@ int init_gemm_bf16_tiled_kernels() {
   static bool done = false;
   if (done) return 0;
 #define M3_TILED_ATTR(G_, C_, L_)                                                                                 \
-  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_>,               \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>,            \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(128, 128, 64)));   \
-  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_>,                \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0>,             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(64, 64, 128)));
   M3_TILED_FOR_ALL(M3_TILED_ATTR)
 #undef M3_TILED_ATTR
+#define M3_GRP_ATTR(BM_, BN_, BK_, P_)                                                                            \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, P_>,  \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(BM_, BN_, BK_)))
+  M3_GRP_ATTR(128, 128, 64, 1); M3_GRP_ATTR(128, 128, 64, 2); M3_GRP_ATTR(64, 64, 128, 1); M3_GRP_ATTR(64, 64, 128, 2);
+#undef M3_GRP_ATTR
   done = true;
   return 0;
 }
@@ -290,18 +365,53 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
   p.m_tiles = cdiv(p.M, bm);
   p.n_tiles = glu ? cdiv(Nout, bn / 2) : cdiv(p.N, bn);
-  dim3 grid(p.m_tiles * p.n_tiles);
+  dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);   // row tiles in groups of 8 (one per XCD), see the kernel
 #define M3_TILED_LAUNCH(G_, C_, L_)                                                                                  \
   if (glu == G_ && conv == C_ && ln == L_) {                                                                         \
     if (big)                                                                                                         \
-      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_>), grid, dim3(256),                       \
+      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>), grid, dim3(256),                    \
                          tiled_lds_bytes(128, 128, 64), stream, p);                                                  \
     else                                                                                                             \
-      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_>), grid, dim3(256),                        \
+      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0>), grid, dim3(256),                     \
                          tiled_lds_bytes(64, 64, 128), stream, p);                                                   \
   }
   M3_TILED_FOR_ALL(M3_TILED_LAUNCH)
 #undef M3_TILED_LAUNCH
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- grouped expert FFN on the tiled core (long batches) ----
+// H = SiLU(X[pos] W1[e]^T + b1[e]) (bf16, sorted rows), Y = H W2[e]^T (fp32, sorted rows; b2, gate, residual and
+// LayerNorm are applied by moe_combine_kernel with one "slab").  hbuf: S*F bf16, ybuf: S*D fp32.
+int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
+                                  int F, const void* w1, const float* b1, const void* w2, int w2_sliced, void* hbuf,
+                                  float* ybuf, hipStream_t stream) {
+  M3_REQUIRE((D & 127) == 0 && (F & 127) == 0, "expert_ffn tiled: idim=%d / hidden=%d must be multiples of 128", D, F);
+  if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
+  // rows per expert ~ S/E: small tiles (4x the workgroups, half the k-steps) until an expert fills 128-row tiles
+  const bool big = S / E >= 192;
+  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+  const int m_slots = cdiv(cdiv(S, bm) + E, 8) * 8;          // upper bound of sum_e ceil(cnt_e / bm), padded to 8 XCDs
+  GemmParams g1;
+  g1.A = x; g1.lda = ldx; g1.W = (const float*)w1; g1.bias = b1; g1.Y = (float*)hbuf; g1.ldy = F;
+  g1.M = S; g1.N = F; g1.K = D; g1.act = ACT_SILU;
+  g1.grp_acc = acc_hist; g1.grp_E = E; g1.grp_pos = pos;
+  g1.n_tiles = cdiv(F, bn); g1.m_tiles = m_slots;
+  GemmParams g2;
+  g2.A = (const float*)hbuf; g2.lda = F; g2.W = (const float*)w2; g2.Y = ybuf; g2.ldy = D;
+  g2.M = S; g2.N = D; g2.K = F; g2.w_sliced = w2_sliced;
+  g2.grp_acc = acc_hist; g2.grp_E = E;
+  g2.n_tiles = cdiv(D, bn); g2.m_tiles = m_slots;
+#define M3_GRP_LAUNCH(BM_, BN_, BK_)                                                                                 \
+  do {                                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, 1>), dim3(m_slots * g1.n_tiles), \
+                       dim3(256), tiled_lds_bytes(BM_, BN_, BK_), stream, g1);                                       \
+    hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, 2>), dim3(m_slots * g2.n_tiles), \
+                       dim3(256), tiled_lds_bytes(BM_, BN_, BK_), stream, g2);                                       \
+  } while (0)
+  if (big) M3_GRP_LAUNCH(128, 128, 64); else M3_GRP_LAUNCH(64, 64, 128);
+#undef M3_GRP_LAUNCH
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -32,6 +32,8 @@ struct GemmParams {
   int act = ACT_NONE;
   float alpha = 1.f;
   const float* resid = nullptr; int ldr = 0;
+  // grouped (per-expert) form of the tiled bf16 kernel: row tiles cut from acc_hist, optional row gather, slice-major W
+  const int32_t* grp_acc = nullptr; int grp_E = 0; const int32_t* grp_pos = nullptr; int w_sliced = 0;
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
@@ -66,6 +68,14 @@ int init_expert_ffn_bf16_kernels();
 int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                             int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* slab,
                             hipStream_t stream);
+// which form launch_expert_ffn_bf16w takes for this shape, and where / in how many slabs its result rows are
+bool expert_ffn_bf16_tiled(int S, int E, int D, int F);
+float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F);
+int expert_ffn_bf16_slices(int S, int E, int D, int F);
+// long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
+int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
+                                  int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced,
+                                  void* hbuf, float* ybuf, hipStream_t stream);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,

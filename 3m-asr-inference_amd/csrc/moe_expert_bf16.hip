@@ -7,6 +7,8 @@
 //   * W1 [E][F][D] and W2 (slice-major [E][F/64][D][64] or reference [E][D][F]) stored bf16: 2.1 MB per touched expert,
 //   * token rows rounded to bf16 once while they are staged in LDS, H = SiLU(. + b1) rounded to bf16 in LDS,
 //   * b1 / b2 / gate / residual / LayerNorm in fp32 (b2 .. LayerNorm live in moe_combine_kernel, shared with fp32).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -152,6 +154,23 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_bf16w_ker
   }
 }
 
+// Long batches run as two grouped GEMMs on the LDS-tiled core instead (gemm_bf16_tiled.hip): the slab form writes and
+// re-reads F/64 partial outputs per row (32 KB per row), which bounds it to ~65 TFLOP/s however many rows an expert has.
+// The tiled form keeps H (bf16, S*F) and the sorted output rows (fp32, S*D) in the SAME workspace region the slabs use.
+bool expert_ffn_bf16_tiled(int S, int E, int D, int F) {
+  static const int min_rows = [] {
+    const char* e = getenv("M3_EXPERT_TILED_MIN_ROWS");
+    return e ? atoi(e) : 1024;
+  }();
+  const size_t slab = expert_ffn_slab_bytes(S, D, F);
+  const size_t need = align_up((size_t)S * F * 2, 256) + (size_t)S * D * 4;
+  return S >= min_rows && (D & 127) == 0 && (F & 127) == 0 && need <= slab;
+}
+float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F) {   // what moe_combine reads
+  return expert_ffn_bf16_tiled(S, E, D, F) ? (float*)((char*)slab + align_up((size_t)S * F * 2, 256)) : slab;
+}
+int expert_ffn_bf16_slices(int S, int E, int D, int F) { return expert_ffn_bf16_tiled(S, E, D, F) ? 1 : F / kExpertSlice; }
+
 int init_expert_ffn_bf16_kernels() {
   static bool done = false;
   if (done) return 0;
@@ -167,6 +186,9 @@ int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const i
   M3_REQUIRE((D & 31) == 0 && D <= 2048, "expert_ffn_bf16w: idim=%d must be a multiple of 32 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_bf16w: ldx=%d must be a multiple of 4", ldx);
+  if (expert_ffn_bf16_tiled(S, E, D, F))
+    return launch_expert_ffn_bf16w_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
+                                         expert_ffn_bf16_rows(slab, S, E, D, F), stream);
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
   const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(bf16_t);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn_bf16w: LDS tile of %zu bytes does not fit", lds_bytes);

@@ -50,7 +50,10 @@ def _plugin(nh, name, fields):
 
 
 def _dtype(nh):
-    return int(nh.config.plugin_data_type) if nh.config is not None else 0
+    """`data_type` field of the emitted plugins = the type of their ACTIVATION tensors.  The reference passes
+    HelperConfig.plugin_data_type; here activations stay fp32 in every mode (the 16-bit mode, --fp16, is a property of
+    the packed plan's GEMM weights), so the op-by-op emission -- the fp32 checker of the fused engine -- is always 0."""
+    return 0
 
 
 def emit_subsampling(nh, sd, p, x, x_len):

@@ -67,9 +67,12 @@ class BuilderHelper:
         self.config = config
         self.logger = logger if logger is not None else trt.Logger(trt.Logger.INFO)
         self.config.log()
-        if config.use_fp16 or config.use_int8 or config.plugin_data_type != 0:
-            # the reference wires these flags but never finished them (builder.py:39-49; fmoe asserts on HALF)
-            raise RuntimeError("only fp32 (plugin_data_type 0) is implemented in this round")
+        # the reference wires --fp16 / --int8 but never finished them (builder.py:39-49; fmoe asserts on HALF).
+        # Here --fp16 (use_fp16 / plugin_data_type HALF) selects the 16-bit weight mode of the engine: bf16 storage and
+        # bf16 MFMA with fp32 accumulation (bf16 is the 16-bit type of CDNA4); int8 / fp8 is not implemented.
+        if config.use_int8 or int(config.plugin_data_type) not in (0, 1):
+            raise RuntimeError("int8 / fp8 calibration is not implemented (fp32 and the 16-bit --fp16 mode are)")
+        self.weight_dtype = "bf16" if (config.use_fp16 or int(config.plugin_data_type) == 1) else "f32"
         self.device = torch.device(device)
         self.profiles = {}
         self.model, self.model_cfg = None, None
@@ -118,6 +121,9 @@ class BuilderHelper:
         nh = self.network_helper
         if not nh.outputs:
             raise RuntimeError("build_engine: no output marked")
+        if self.weight_dtype != self.model_cfg.weight_dtype:
+            import dataclasses
+            self.model_cfg = dataclasses.replace(self.model_cfg, weight_dtype=self.weight_dtype)
         packed = pack_weights(self.model, self.model_cfg)
         extra = getattr(self, "output_bias", None)            # e.g. -log prior (builder.py:83-88)
         add_front_back_end(packed, self.model_cfg, cmvn=getattr(self, "cmvn", None), output_bias=extra)
@@ -131,7 +137,10 @@ class BuilderHelper:
         err = float(((fused - ref).abs() * valid.unsqueeze(-1)).max())
         scale = float(ref.abs().max())
         self.logger.log(trt.Logger.INFO, "[Builder] fused engine vs op-by-op emission: max abs diff %.3e (max |logit| %.3e)" % (err, scale))
-        if not err <= 1e-3 * max(scale, 1.0):
+        # fp32 plan: the fused kernels must reproduce the op-by-op emission to 1e-3; a bf16 plan is compared with the fp32
+        # emission, so the bound is the bf16 tolerance of tests/test_bf16_gpu.py plus room for a flipped top-1 expert
+        tol = 1e-3 if self.weight_dtype == "f32" else 1e-1
+        if not err <= tol * max(scale, 1.0):
             raise RuntimeError("build_engine: fused engine disagrees with the emitted network (%.3e)" % err)
         if engine_name is not None:
             save_plan(engine_name, self.model_cfg, packed,

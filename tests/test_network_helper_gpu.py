@@ -77,3 +77,29 @@ def test_builder_and_infer_cli_round_trip(tmp_path):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "infer.py"), "-p", plan, "-i", os.path.join(d, "feat.npy"),
                                    "-o", os.path.join(d, "want.npy")], env=env, text=True)
     assert "time=" in out and "torch.allclose result:True" in out
+
+
+def test_builder_fp16_flag_writes_a_bf16_plan(tmp_path):
+    """--fp16 (reference builder.py:160, never finished there) = the 16-bit weight mode: bf16 GEMM weights in the plan,
+    about half the bytes, and infer.py runs it."""
+    d = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "3m-asr-inference_amd"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_checkpoint.py"), "--out-dir", d,
+                           "--tiny", "--seed", "3"], env=env)
+    p32, p16 = os.path.join(d, "enc32.plan"), os.path.join(d, "enc16.plan")
+    common = [sys.executable, os.path.join(ROOT, "builder.py"), "-c", os.path.join(d, "config.yaml"), "-m",
+              os.path.join(d, "model.pt"), "--opt-shape", "2x64"]
+    subprocess.check_output(common + ["-o", p32], env=env, text=True)
+    out = subprocess.check_output(common + ["-o", p16, "--fp16"], env=env, text=True)
+    assert "fused engine vs op-by-op emission" in out
+    from m3asr.plan import load_plan, is_gemm_weight
+    cfg16, packed16, _ = load_plan(p16)
+    assert cfg16.weight_dtype == "bf16"
+    assert all((v.dtype == torch.bfloat16) == is_gemm_weight(k) for k, v in packed16.items())
+    pe_bytes = packed16["pe"].numel() * 4
+    assert (os.path.getsize(p16) - pe_bytes) < 0.75 * (os.path.getsize(p32) - pe_bytes)
+    feat = np.random.default_rng(0).random((1, 206, 40), dtype=np.float32)
+    np.save(os.path.join(d, "feat.npy"), feat)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "infer.py"), "-p", p16, "-i", os.path.join(d, "feat.npy")],
+                                  env=env, text=True)
+    assert "time=" in out and "outputs.shape:(1, 50, 16)" in out

@@ -68,6 +68,18 @@ def main():
                                            "frac_of_157TF_fp32_mfma": round(flops / t / 157.3e12, 3),
                                            "rows_per_expert": S // E,
                                            "note": "includes the index + combine launches of m3_moe_expert_ffn"}
+    # the same in the bf16-weight mode (bf16 MFMA, fp32 accumulate): dense MFMA peak 2.5 PFLOP/s
+    w1h, w2h = w1.to(torch.bfloat16), w2.to(torch.bfloat16)
+    for S in (2048, 16384):
+        gate = (torch.arange(S, dtype=torch.int32) % E).to(dev)
+        x = torch.randn(S, D, generator=g).to(dev)
+        ws = torch.empty(ops.moe_expert_workspace_size(S, E, D, F), dtype=torch.uint8, device=dev)
+        t = timed(lambda: ops.moe_expert_ffn(x, gate, w1h, b1, w2h, b2, workspace=ws), iters=10)
+        flops = 4.0 * D * F * S
+        out["expert_ffn_bf16_S=%d" % S] = {"ms": round(t * 1e3, 3), "TFLOPs": round(flops / t / 1e12, 2),
+                                           "frac_of_2500TF_bf16_mfma": round(flops / t / 2.5e15, 4),
+                                           "rows_per_expert": S // E,
+                                           "note": "includes the index + combine launches of m3_moe_expert_ffn_bf16"}
     print(json.dumps(out))
 
 
