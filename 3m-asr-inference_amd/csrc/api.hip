@@ -53,8 +53,8 @@ int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, 
   if (w_bf16) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
   else rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
   if (rc) return rc;
-  const float* rows = w_bf16 ? expert_ffn_bf16_rows(w.slab, S, E, D, F) : w.slab;
-  const int n_slices = w_bf16 ? expert_ffn_bf16_slices(S, E, D, F) : F / kExpertSlice;
+  const float* rows = w_bf16 ? expert_ffn_bf16_rows(w.slab, S, E, D, F) : expert_ffn_f32_rows(w.slab, S, E, D, F);
+  const int n_slices = w_bf16 ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F);
   return launch_moe_combine(rows, n_slices, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps,
                             y, S, D, stream);
 }

@@ -392,14 +392,16 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       });
     }
     const bool e16 = c.weight_dtype == M3_BF16;
-    add_stage(e, pfx + "moe_local.expert", (e16 && expert_ffn_bf16_tiled(S, E, D, F)) ? 2 : 1, [=](hipStream_t s) {
+    const bool etiled = e16 ? expert_ffn_bf16_tiled(S, E, D, F) : expert_ffn_f32_tiled(S, E, D, F);
+    add_stage(e, pfx + "moe_local.expert", etiled ? 2 : 1, [=](hipStream_t s) {
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     });
     }
-    const bool e16c = c.weight_dtype == M3_BF16 && !fused_route;
-    const float* erows = e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : mw.slab;
-    const int eslices = e16c ? expert_ffn_bf16_slices(S, E, D, F) : F / kExpertSlice;
+    // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
+    const bool e16c = c.weight_dtype == M3_BF16;
+    const float* erows = fused_route ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
+    const int eslices = fused_route ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
     });
@@ -517,6 +519,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_expert_ffn_kernels()) return rc;
   if (int rc = init_expert_ffn_bf16_kernels()) return rc;
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
+  if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
   const Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   e->B = B; e->T = T; e->Tp = Tp; e->S = B * Tp;

@@ -63,6 +63,15 @@ int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                           int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, float* slab,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream);
+// long batches (S >= 1024): two grouped LDS-tiled fp32 GEMMs (moe_expert_tiled_f32.hip); launch_expert_ffn_f32 switches
+// to it by itself; these tell the combine step where / in how many slabs the result rows are
+bool expert_ffn_f32_tiled(int S, int E, int D, int F);
+float* expert_ffn_f32_rows(float* slab, int S, int E, int D, int F);
+int expert_ffn_f32_slices(int S, int E, int D, int F);
+int init_expert_ffn_f32_tiled_kernels();
+int launch_expert_ffn_f32_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
+                                int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced,
+                                float* hbuf, float* ybuf, hipStream_t stream);
 // bf16 weights (w1 [E][F][D], w2 as above), fp32 rows in / fp32 slab out (moe_expert_bf16.hip)
 int init_expert_ffn_bf16_kernels();
 int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,

@@ -242,6 +242,9 @@ int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int
   M3_REQUIRE((D & 15) == 0 && D <= 2048, "expert_ffn: idim=%d must be a multiple of 16 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn: ldx=%d must be a multiple of 4", ldx);
+  if (ln_gamma == nullptr && expert_ffn_f32_tiled(S, E, D, F))   // long batches: two grouped LDS-tiled GEMMs
+    return launch_expert_ffn_f32_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
+                                       expert_ffn_f32_rows(slab, S, E, D, F), stream);
   // rows per tile: small batches keep LDS small (more workgroups per CU -> more bytes in flight)
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
   const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(float);

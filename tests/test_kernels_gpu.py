@@ -183,7 +183,10 @@ def test_linear_concat_router():
 # ------------------------------------------------------------------------------------------ expert FFN
 @pytest.mark.parametrize("S,E,D,Fh,mode", [(50, 32, 512, 1024, "uniform"), (50, 32, 512, 1024, "all_one"),
                                            (200, 32, 512, 1024, "uniform"), (1090, 32, 512, 1024, "with_dropped"),
-                                           (23, 4, 32, 64, "with_dropped"), (600, 64, 512, 1024, "uniform")])
+                                           (23, 4, 32, 64, "with_dropped"), (600, 64, 512, 1024, "uniform"),
+                                           # >= 1024 rows: two grouped LDS-tiled GEMMs (64- and 128-row tiles)
+                                           (2048, 32, 512, 1024, "all_one"), (8192, 32, 512, 1024, "uniform"),
+                                           (6500, 8, 512, 1024, "with_dropped")])
 def test_fmoe_expert(S, E, D, Fh, mode):
     rng = np.random.default_rng(S + E)
     g = {"uniform": rng.integers(0, E, S), "all_one": np.full(S, 3), "with_dropped": rng.integers(-1, E, S)}[mode]
