@@ -238,12 +238,18 @@ def main():
             acc_t += np.array([a.elapsed_time(b) for a, b in evs])
         dur = acc_t / passes * 1e-3
         achieved = float((bytes_alg / dur).mean() / 1e9)
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs) of the
+        # SAME kernel at the same shape with HBM-cold weights (tools/pmc_expert.py -> profiles/r01_pmc_expert.json; the
+        # full bench.py segfaults inside the profiler's counter collection on this pool), scaled by the touched-expert
+        # count of this run (the probe's routing touched 25.33 experts per layer)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
         kname = "expert_ffn_bf16w_kernel" if cfg.weight_dtype == "bf16" else "expert_ffn_f32_kernel"
-        if os.path.exists(pmc) and cfg.weight_dtype == "f32" and B == 1 and T == 206:          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same command)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_expert.json")
+        if os.path.exists(pmc) and B == 1 and T == 206:
             try:
-                traffic = json.load(open(pmc))["kernels"]["void m3::expert_ffn_f32_kernel<1>"]["traffic_bytes_per_launch"]
+                ent = json.load(open(pmc))[cfg.weight_dtype]
+                per = [v for k, v in ent["kernels"].items() if "expert_ffn" in k][0]["traffic_bytes_per_launch"]
+                traffic = int(per * float(np.mean(touched)) / ent["meta"]["experts_touched_mean"])
             except Exception:
                 traffic = None
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
