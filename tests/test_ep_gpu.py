@@ -34,6 +34,21 @@ def test_ep_world1_equals_fused_engine():
     assert torch.allclose(fused, staged, rtol=1e-4, atol=1e-4)
 
 
+def test_ep_world1_bf16_equals_engine():
+    """16-bit mode (BASELINE.json configs[3]: bf16 expert parallel): the EP driver feeds bf16 expert weights to
+    m3_moe_expert_ffn_bf16; with one rank it must reproduce the bf16 engine bit for bit (same kernels, same order),
+    for the slab form (S < 1024) and for the two grouped tiled GEMMs (S >= 1024)."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1, weight_dtype="bf16")
+    w = make_weights(cfg, seed=4)
+    for B, T in ((2, 120), (16, 400)):                      # 58 rows (slab form); 1584 rows, 1200 routed (tiled form on both sides)
+        feat = torch.rand(B, T, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
+        fl = torch.tensor([[T - 13 * i for i in range(B)]], dtype=torch.int32).cuda()
+        eng = Engine.from_state_dict(cfg, w)
+        want = eng(feat, fl).clone()
+        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w))
+        assert torch.equal(ep.forward(feat, fl), want)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
