@@ -76,6 +76,7 @@ struct m3_engine {
   int B = 0, T = 0, Tp = 0, S = 0;
   const float* feat = nullptr; const int32_t* feat_len = nullptr; float* logits = nullptr;
   void* ws = nullptr; size_t ws_bytes = 0;
+  float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
   std::vector<Stage> stages;
   std::unordered_map<std::string, Buf> buffers;
   int n_kernels = 0;
@@ -202,6 +203,7 @@ struct Plan {
   float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
   void* moe_ws; size_t moe_ws_bytes;
+  float* splitk; size_t splitk_bytes;   // split-K partials of conv2 / subsampling Linear (fp32 plans, short inputs)
   float* taps;                          // [n_blocks_total][S][D] when debug_taps
   float* pfold;                         // [n_blocks_total][Tp][D] when fold_pos_proj
   size_t bytes;
@@ -234,6 +236,19 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.gate_val = cv.take<float>((size_t)c.num_blocks * S);
   p.moe_ws_bytes = carve_moe_workspace(nullptr, S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
   p.moe_ws = cv.take<char>(p.moe_ws_bytes * (size_t)(c.debug_taps ? c.num_blocks : 1));
+  {
+    size_t n1 = 0, n2 = 0;
+    if (c.weight_dtype == M3_F32) {
+      GemmParams g;   // conv2 as implicit GEMM
+      g.mode = GEMM_A_CONV3X3S2; g.lda = 4; g.conv_C = D; g.M = S * F2; g.N = D; g.K = 9 * D; g.ldy = D;
+      gemm_f32_splitk_plan(g, &n1);
+      GemmParams l;   // Linear(C*F2 -> D)
+      l.lda = F2 * D; l.M = S; l.N = D; l.K = F2 * D; l.ldy = D;
+      gemm_f32_splitk_plan(l, &n2);
+    }
+    p.splitk_bytes = n1 > n2 ? n1 : n2;
+    p.splitk = p.splitk_bytes ? cv.take<float>(p.splitk_bytes / sizeof(float)) : nullptr;
+  }
   p.taps = c.debug_taps ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * S * D) : nullptr;
   p.pfold = nullptr;
   p.bytes = cv.off;
@@ -251,6 +266,12 @@ static void add_stage(m3_engine* e, const std::string& name, int kernels, std::f
 // fp32_weights: the router GEMMs keep fp32 weights in every mode (a flipped top-1 is a discrete error)
 static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool fp32_weights = false) {
   p.w_bf16 = (!fp32_weights && e->cfg.weight_dtype == M3_BF16) ? 1 : 0;
+  size_t need = 0;
+  if (gemm_f32_splitk_plan(p, &need) >= 2 && e->splitk_ws != nullptr && need <= e->splitk_bytes) {
+    float* ws = e->splitk_ws; const size_t wsb = e->splitk_bytes;
+    add_stage(e, name, 2, [p, ws, wsb](hipStream_t s) { return launch_gemm_f32_splitk(p, ws, wsb, s); });
+    return;
+  }
   add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); });
 }
 
@@ -525,6 +546,8 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->B = B; e->T = T; e->Tp = Tp; e->S = B * Tp;
   e->feat = feat; e->feat_len = feat_len; e->logits = logits; e->ws = workspace; e->ws_bytes = workspace_bytes;
   e->stages.clear(); e->buffers.clear(); e->n_kernels = 0; e->graph_valid = false;
+  e->splitk_ws = pl.splitk; e->splitk_bytes = pl.splitk_bytes;
+  if (int rc = init_gemm_f32_splitk_kernels()) return rc;
   const int S = e->S, D = c.attention_dim, De = c.embed_dim;
 
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)

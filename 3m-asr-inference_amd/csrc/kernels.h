@@ -39,6 +39,10 @@ struct GemmParams {
 };
 int launch_gemm_f32(const GemmParams& p, hipStream_t stream);   // dispatches to launch_gemm_bf16w when p.w_bf16
 int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
+// deep-K, few-tile fp32 problems (conv2 / subsampling Linear at short inputs): split-K tiled kernel + reduce (gemm_f32_splitk.hip)
+int gemm_f32_splitk_plan(const GemmParams& p, size_t* ws_bytes);   // number of K ranges (0 = not applicable) and workspace
+int launch_gemm_f32_splitk(const GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream);
+int init_gemm_f32_splitk_kernels();
 int init_gemm_bf16_tiled_kernels();   // once, outside graph capture (dynamic-LDS opt-in of the tiled kernels)
 
 // ---- MoE indexing / scatter / gather (moe_index.hip) ----
