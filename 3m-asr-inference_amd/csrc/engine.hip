@@ -376,8 +376,25 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     const float* gv = c.keep_expert_output ? nullptr : gval;
-    const bool fused_route = c.fuse_route && world == 1 && S <= 256 && (E == 16 || E == 32 || E == 64);
-    if (fused_route) {
+    const bool fused_route = c.fuse_route == 1 && world == 1 && S <= 256 && (E == 16 || E == 32 || E == 64);
+    // fuse_route = 2 ("split route"): the embed half of every layer's router product comes from one GEMM per forward
+    // ("router_e_all"), the x half is a K = D GEMM with norm_ff folded in (output-side LayerNorm, the embed half added as
+    // the epilogue residual) instead of the K = De + D GEMM with a LayerNorm prologue, and the expert kernel applies
+    // norm_ff while it gathers rows, so xn is never materialised
+    const bool split_route = c.fuse_route == 2 && world == 1 && S < 1024 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
+    if (split_route) {
+      GemmParams r;
+      r.A = x; r.lda = D; r.W = w.router_x.w; r.bias = w.router_x.b; r.ln_wsum = w.router_x.wsum; r.ln_eps = eps;
+      r.Y = rl; r.ldy = Etot; r.M = S; r.N = Etot; r.K = D;
+      r.resid = pl.eall + (size_t)layer * E; r.ldr = c.num_blocks * E;
+      add_gemm(e, pfx + "moe_router", r, true);
+      add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
+        return launch_moe_gate_index(rl, Etot, lens, Tp, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
+      });
+      add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+        return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
+      });
+    } else if (fused_route) {
       // router (x half, norm_ff folded; embed half precomputed for all layers by "router_e_all") + SoftmaxTopK +
       // ScatterMapping in ONE launch; the expert kernel applies norm_ff itself while it gathers rows
       const float* wx = w.router_x.w; const float* wsum = w.router_x.wsum; const float* rb = w.router_x.b;
@@ -421,8 +438,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     }
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
     const bool e16c = c.weight_dtype == M3_BF16;
-    const float* erows = fused_route ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
-    const int eslices = fused_route ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
+    const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
+    const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
     });
@@ -580,8 +597,9 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); });
   }
   // embed half of every layer's router product in one GEMM: emb does not change across the main blocks
-  if (c.fuse_route && (c.ep_world_size <= 1) && S <= 256 &&
-      (c.num_experts == 16 || c.num_experts == 32 || c.num_experts == 64)) {
+  if ((c.fuse_route == 2 && c.ep_world_size <= 1 && S < 1024) ||
+      (c.fuse_route == 1 && (c.ep_world_size <= 1) && S <= 256 &&
+       (c.num_experts == 16 || c.num_experts == 32 || c.num_experts == 64))) {
     GemmParams g;
     g.A = pl.emb; g.lda = De; g.W = e->router_e_all; g.Y = pl.eall; g.ldy = c.num_blocks * c.num_experts;
     g.M = S; g.N = c.num_blocks * c.num_experts; g.K = De;

@@ -41,7 +41,10 @@ class Engine:
                  fuse_route=False):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
-        multiple IExecutionContexts per engine)."""
+        multiple IExecutionContexts per engine).
+        fuse_route: 0 / False = staged route (router GEMM on cat([embed, x]) with a LayerNorm prologue that writes xn);
+        1 / True = router + top-1 + index in one single-workgroup launch (S <= 256); 2 = split route (embed half of all
+        routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel)."""
         self.lib = _lib.load()
         from .plan import EXPERT_SLICE
         assert self.lib.m3_moe_expert_slice() == EXPERT_SLICE, "plan.EXPERT_SLICE out of sync with libm3asr_hip.so"
@@ -57,7 +60,7 @@ class Engine:
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
             table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
-        ec = _engine_config(cfg, fold_pos_proj, debug_taps, fuse_route and cfg.ep_world_size <= 1)
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())

@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--routing", choices=["balanced", "random"], default="balanced",
                     help="balanced: calibrate the synthetic router weights so tokens spread over the experts "
                          "(a trained 3M-ASR router is load-balanced by its aux losses); random: raw N(0,0.5) init")
+    ap.add_argument("--route-mode", choices=["staged", "fused", "split"], default=None,
+                    help="router path of the engine (default: staged; see m3asr/engine.py)")
     ap.add_argument("--fuse-route", action="store_true",
                     help="router + SoftmaxTopK + ScatterMapping as one single-workgroup launch per layer (275 instead of "
                          "292 kernels; measured 2-3 %% slower than the staged path, so off by default)")
@@ -148,10 +150,11 @@ def main():
     if args.routing == "balanced":
         eng.bind(feat, feat_len)
         balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
-    if args.fuse_route:                      # rebuild from the calibrated state_dict
+    route = {"staged": 0, "fused": 1, "split": 2}[args.route_mode] if args.route_mode else (1 if args.fuse_route else 0)
+    if route:                                # rebuild from the calibrated state_dict
         del eng
         torch.cuda.empty_cache()
-        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=True)
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route)
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         weights = None
     eng.bind(feat, feat_len)
@@ -161,7 +164,7 @@ def main():
     # extra execution contexts: same weights, own utterance / stream / workspace / graph
     ctxs = [eng]
     for si in range(1, args.streams):
-        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=args.fuse_route)
+        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=route)
         f2 = torch.from_numpy(np.random.default_rng(5000 + 97 * rank + si).random((B, T, cfg.input_dim), dtype=np.float32)).to(dev)
         c.bind(f2, feat_len.clone())
         ctxs.append(c)
@@ -315,7 +318,7 @@ def main():
                           "parallelism": "replicas x%d" % world, "streams_per_gpu": len(ctxs),
                           "latency_ms_one_stream": round(latency_ms, 4), "hip_graph": use_graph,
                           "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
-                          "routing": args.routing},
+                          "routing": args.routing, "route_mode": ["staged", "fused", "split"][route]},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:

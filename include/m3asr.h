@@ -236,7 +236,9 @@ typedef struct m3_engine_config {
   int32_t fold_pos_proj;         /* 1 = linear_pos(pos_emb) computed once per T' at shape set-up */
   int32_t debug_taps;            /* 1 = keep every block's output (the reference's DumpTensor taps) */
   int32_t log_softmax_out;       /* 1 = output log_softmax(logits) (+ "output_bias" weight entry if present, e.g. -log prior) */
-  int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank) */
+  int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank);
+                                  * 2 = split route: embed half of all routers in one GEMM, x half with folded LayerNorm,
+                                  *     norm_ff applied by the expert kernel (1 rank, fp32) */
   int32_t weight_dtype;          /* M3_F32 / M3_BF16: storage of the GEMM weights (linear / point-wise conv /
                                   * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32 */
 } m3_engine_config;

@@ -100,6 +100,34 @@ def test_fused_and_staged_route_paths_agree():
     assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
 
 
+def test_split_route_path_agrees_with_staged():
+    """fuse_route=2: embed half of every router in one GEMM per forward, x half as a K = D GEMM with norm_ff folded in,
+    norm_ff applied by the expert kernel while gathering (xn never materialised): same routing, logits within fp32 noise;
+    also on the golden cfg-2 fixture (18 layers, 32 experts)."""
+    cfg = EncoderConfig(num_blocks=3, embed_blocks=1)
+    w = make_weights(cfg, seed=8)
+    feat = torch.rand(2, 206, cfg.input_dim, generator=torch.Generator().manual_seed(3)).cuda()
+    fl = torch.tensor([[206, 131]], dtype=torch.int32).cuda()
+    a = Engine.from_state_dict(cfg, w, fuse_route=2)
+    b = Engine.from_state_dict(cfg, w, fuse_route=0)
+    ya, yb = a(feat, fl).clone(), b(feat, fl).clone()
+    assert "router_e_all" in a.stage_names() and "router_e_all" not in b.stage_names()
+    for i in range(cfg.num_blocks):
+        assert torch.equal(a.buffer("blocks.%d.gate_idx" % i, torch.int32), b.buffer("blocks.%d.gate_idx" % i, torch.int32))
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+
+
+def test_split_route_matches_golden_cfg2(golden):
+    cfg, z = golden("cfg2")
+    w = make_weights(cfg, seed=int(z["weight_seed"]))
+    eng, out = _run(cfg, w, torch.from_numpy(z["feat"]), torch.from_numpy(z["feat_len"]), fuse_route=2)
+    _check(out, torch.from_numpy(z["logits"]), z["out_len"])
+    valid = np.arange(out.shape[1])[None, :] < z["out_len"][:, None]
+    for i in range(z["gate_idx"].shape[0]):
+        gi = eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().numpy().reshape(valid.shape)
+        assert np.array_equal(gi[valid], z["gate_idx"][i][..., 0][valid])
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()
