@@ -37,11 +37,13 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
 
 
 class Engine:
-    def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=False, debug_taps=False,
+    def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
                  fuse_route=False):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
+        fold_pos_proj (default on): p = linear_pos(pos_emb[:T']) of every block depends on the weights and on T' only, not
+        on the input, so it is computed once when a shape is bound (constant folding) instead of in every forward.
         fuse_route: 0 / False = staged route (router GEMM on cat([embed, x]) with a LayerNorm prologue that writes xn);
         1 / True = router + top-1 + index in one single-workgroup launch (S <= 256); 2 = split route (embed half of all
         routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel)."""

@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=18)
     ap.add_argument("--experts", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--fold-pos", action="store_true", help="precompute linear_pos(pos_emb) per shape")
+    ap.add_argument("--no-fold-pos", dest="fold_pos", action="store_false",
+                    help="recompute linear_pos(pos_emb[:T']) in every forward (it is input-independent: the engine folds it "
+                         "at shape-binding time by default, like a constant-folded initializer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--streams", type=int, default=4,

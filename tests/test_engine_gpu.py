@@ -72,7 +72,7 @@ def test_engine_graph_replay_and_fold_are_bit_identical():
     w = make_weights(cfg, seed=2)
     feat = torch.rand(1, 206, cfg.input_dim, generator=torch.Generator().manual_seed(1)).cuda()
     fl = torch.tensor([[206]], dtype=torch.int32).cuda()
-    eng = Engine.from_state_dict(cfg, w)
+    eng = Engine.from_state_dict(cfg, w, fold_pos_proj=False)
     eager = eng(feat, fl).clone()
     for _ in range(3):
         eng.forward(use_graph=True)
