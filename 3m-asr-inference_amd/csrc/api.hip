@@ -119,7 +119,7 @@ int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_pe
   return launch_softmax_top1(logits, ld, len, rows_per_batch, S, width, idx, value, (hipStream_t)stream);
 }
 
-int m3_linear(const m3_linear_desc* d, m3_stream stream) {
+static int linear_params(const m3_linear_desc* d, GemmParams* out) {
   M3_REQUIRE(d != nullptr, "linear: null descriptor");
   GemmParams p;
   p.A = d->a; p.lda = d->lda;
@@ -133,6 +133,26 @@ int m3_linear(const m3_linear_desc* d, m3_stream stream) {
   p.ln_wsum = d->ln_wsum; p.ln_wbeta = d->ln_wbeta;
   p.row_len = d->len; p.rows_per_batch = d->rows_per_batch; p.mask_in = d->mask_in; p.mask_out = d->mask_out;
   p.act = d->act; p.alpha = d->alpha; p.resid = d->resid; p.ldr = d->ldr;
+  *out = p;
+  return 0;
+}
+int m3_linear(const m3_linear_desc* d, m3_stream stream) {
+  GemmParams p;
+  if (int rc = linear_params(d, &p)) return rc;
+  return launch_gemm_f32(p, (hipStream_t)stream);
+}
+size_t m3_linear_workspace_size(const m3_linear_desc* d) {
+  GemmParams p;
+  size_t need = 0;
+  if (linear_params(d, &p) == 0) gemm_f32_splitk_plan(p, &need);
+  return need;
+}
+int m3_linear_ws(const m3_linear_desc* d, void* workspace, size_t workspace_bytes, m3_stream stream) {
+  GemmParams p;
+  if (int rc = linear_params(d, &p)) return rc;
+  size_t need = 0;
+  if (gemm_f32_splitk_plan(p, &need) >= 2 && workspace != nullptr && workspace_bytes >= need)
+    return launch_gemm_f32_splitk(p, (float*)workspace, workspace_bytes, (hipStream_t)stream);
   return launch_gemm_f32(p, (hipStream_t)stream);
 }
 

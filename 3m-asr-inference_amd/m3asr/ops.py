@@ -122,7 +122,7 @@ def softmax_top1(logits, lens=None, rows_per_batch=0):
 
 # ---------------------------------------------------------------------------------------- dense
 def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows_per_batch=0, mask_in=False,
-           mask_out=False, alpha=1.0, resid=None, out=None, ln_folded=None):
+           mask_out=False, alpha=1.0, resid=None, out=None, ln_folded=None, split_k=False):
     """y = resid + alpha * mask_out(act(LN(mask_in(cat[a,a2])) @ w^T + bias)); a (M,K1), w (N,K).
     ln = (gamma, beta, eps): affine LayerNorm prologue.  ln_folded = (wsum, wbeta or None, eps): w / bias already
     contain the LayerNorm affine (plan.fold_layernorm) and the kernel normalises its output."""
@@ -155,6 +155,11 @@ def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows
     d.act, d.alpha = act, float(alpha)
     if resid is not None:
         d.resid, d.ldr = resid.data_ptr(), resid.stride(0)
+    if split_k:        # deep-K / few-tile problems: split-K kernel + reduce through a scratch workspace
+        need = lib.m3_linear_workspace_size(C.byref(d))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=a.device)
+        check(lib.m3_linear_ws(C.byref(d), _p(ws), need, _stream()), "m3_linear_ws")
+        return y
     check(lib.m3_linear(C.byref(d), _stream()), "m3_linear")
     return y
 

@@ -163,6 +163,11 @@ typedef struct m3_linear_desc {
   int32_t weight_dtype;
 } m3_linear_desc;
 int m3_linear(const m3_linear_desc* desc, m3_stream stream);
+/* The same with a caller-owned workspace: deep-K problems with few output tiles (K >= 4096, e.g. the subsampling Linear of
+ * a single utterance) run as a split-K tiled kernel + fixed-order reduce when m3_linear_workspace_size(desc) > 0 bytes
+ * are provided; otherwise identical to m3_linear. */
+size_t m3_linear_workspace_size(const m3_linear_desc* desc);
+int m3_linear_ws(const m3_linear_desc* desc, void* workspace, size_t workspace_bytes, m3_stream stream);
 
 /* LayerNormPluginDynamic (layer_norm_plugin.cpp:78-113) -- with eps, as PyTorch. */
 int m3_layer_norm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int dim,

@@ -117,6 +117,22 @@ def test_linear_plain(M, N, K):
     close(y, F.linear(a, w, b), 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(50, 512, 9728, _lib.ACT_NONE), (450, 512, 4608, _lib.ACT_RELU),
+                                         (7, 64, 4096, _lib.ACT_SILU), (130, 100, 8192, _lib.ACT_NONE)])
+def test_linear_split_k(M, N, K, act):
+    """Deep-K, few-tile problems through m3_linear_ws: split-K tiled kernel + fixed-order reduce."""
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    d = _lib.LinearDesc()
+    d.a, d.lda, d.w, d.M, d.N, d.K, d.ldy = 1, K, 1, M, N, K, N        # sizes only (pointers are not read)
+    assert _lib.load().m3_linear_workspace_size(d) > 0
+    y = ops.linear(dev(a), dev(w), dev(b), act=act, alpha=0.5, split_k=True)
+    want = F.linear(a.double(), w.double(), b.double())
+    want = {_lib.ACT_NONE: want, _lib.ACT_RELU: F.relu(want), _lib.ACT_SILU: F.silu(want)}[act] * 0.5
+    close(y, want.float(), 3e-5, 3e-5)
+    y2 = ops.linear(dev(a), dev(w), dev(b), act=act, alpha=0.5, split_k=True)
+    assert torch.equal(y, y2)                                           # deterministic (no atomics)
+
+
 def test_linear_epilogues():
     M, N, K, T = 100, 1024, 512, 50
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
