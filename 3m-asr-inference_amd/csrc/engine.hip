@@ -416,8 +416,9 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
     add_gemm(e, pfx + "moe_router", r, true);
     // "moe_local.*" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
-    if (world == 1 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
-      // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch
+    if (world == 1 && S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
+      // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch (a single workgroup: right for a
+      // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
         return launch_moe_gate_index(rl, Etot, lens, Tp, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
       });

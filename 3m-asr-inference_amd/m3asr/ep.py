@@ -130,7 +130,7 @@ class ExpertParallelEncoder:
         eng, cfg = self.eng, self.eng.cfg
         logits = eng.bind(feat, feat_len)
         names = eng.stage_names()
-        if "blocks.0.moe_router" not in names:
+        if "blocks.0.moe_router" not in names or "router_e_all" in names:   # fused / split route engines never write xn
             raise RuntimeError("ExpertParallelEncoder needs an engine built with fuse_route=False (or ep_world_size > 1)")
         S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
         cur = 0
