@@ -388,6 +388,8 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   // workgroups than fit at once (2 per CU) only serialise: then prefer fatter tiles
   int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
   while (mt < 4 && 16 * mt < p.M && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) > 512) mt *= 2;
+  // narrow outputs over many rows (the router: N = 32 experts, S ~ 2000 rows): fat row tiles would leave most CUs idle
+  while (mt > 1 && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) < 256) mt /= 2;
   p.n_tiles = cdiv(Nout, 16);
   p.m_tiles = cdiv(p.M, 16 * mt);
   p.xcd_swizzle = (p.n_tiles % 8 == 0) ? 1 : 0;
