@@ -29,6 +29,8 @@
 //    the A fragments already in registers, so LayerNorm costs no extra memory round trip and no barrier.
 //  * LN_PRO (generic m3_linear with gamma / beta): statistics (two-pass) + affine applied to the A
 //    fragments before the MFMAs; can also write the normalised rows out (ln_out).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -359,6 +361,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   }
 }
 
+int launch_gemm_f32_tiled(const GemmParams& p, hipStream_t stream);   // gemm_f32_tiled.hip
+bool gemm_f32_tiled_supports(const GemmParams& p);
+static int f32_tiled_min_rows() {   // below this many rows the K-split kernel fills the chip better (M3_TILED_MIN_ROWS overrides)
+  static const int v = [] {
+    const char* e = getenv("M3_TILED_MIN_ROWS");
+    return e ? atoi(e) : 384;
+  }();
+  return v;
+}
+
 int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   if (pin.w_bf16) return launch_gemm_bf16w(pin, stream);
   GemmParams p = pin;
@@ -383,6 +395,10 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   M3_REQUIRE(p.ln_out == nullptr || ln == LN_PRO, "gemm: ln_out needs the affine LayerNorm prologue");
   M3_REQUIRE(!(ln == LN_EPI && p.mask_in) || p.ln_wbeta, "gemm: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm: mask needs row_len");
+  // long batches: LDS-tiled kernel (everything but the affine-LayerNorm / concat router GEMM, whose output is 32 wide)
+  // (needs enough 64 x 64 tiles to occupy the chip: below ~160 the K-split kernel's many small workgroups win)
+  if (p.M >= f32_tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_f32_tiled_supports(p))
+    return launch_gemm_f32_tiled(p, stream);
   const int Nout = glu ? p.N / 2 : p.N;
   // row tile: 16*MT rows per workgroup; short inputs are cut into 16-row tiles to fill the chip, but more
   // workgroups than fit at once (2 per CU) only serialise: then prefer fatter tiles

@@ -271,7 +271,9 @@ int launch_gemm_bf16w(const GemmParams& pin, hipStream_t stream) {
   if (ln) M3_REQUIRE(p.mode == GEMM_A_PLAIN && p.K <= 2047, "gemm_bf16w: LayerNorm needs plain A with K < 2048");
   M3_REQUIRE(!(ln && p.mask_in) || p.ln_wbeta, "gemm_bf16w: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm_bf16w: mask needs row_len");
-  if (p.M >= tiled_min_rows() && gemm_bf16w_tiled_supports(p)) return launch_gemm_bf16w_tiled(p, stream);   // long batches: LDS-tiled 128 x 256 kernel
+  // long batches: LDS-tiled kernel, when there are enough 64 x 64 tiles to occupy the chip
+  if (p.M >= tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_bf16w_tiled_supports(p))
+    return launch_gemm_bf16w_tiled(p, stream);
   const int Nout = glu ? p.N / 2 : p.N;
   int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
   while (mt < 4 && 16 * mt < p.M && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) > 512) mt *= 2;

@@ -43,7 +43,8 @@ int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
 int gemm_f32_splitk_plan(const GemmParams& p, size_t* ws_bytes);   // number of K ranges (0 = not applicable) and workspace
 int launch_gemm_f32_splitk(const GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream);
 int init_gemm_f32_splitk_kernels();
-int init_gemm_bf16_tiled_kernels();   // once, outside graph capture (dynamic-LDS opt-in of the tiled kernels)
+int init_gemm_bf16_tiled_kernels();
+int init_gemm_f32_tiled_kernels();    // same for the fp32 tiled kernels (gemm_f32_tiled.hip)   // once, outside graph capture (dynamic-LDS opt-in of the tiled kernels)
 
 // ---- MoE indexing / scatter / gather (moe_index.hip) ----
 int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist,

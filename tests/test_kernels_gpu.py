@@ -314,3 +314,42 @@ def test_small_plugins():
           m1 @ m3.transpose(-1, -2), 1e-5, 1e-5)
     xc, wc, bc = rnd(2, 8, 21, seed=10), rnd(8, 1, 15, seed=11), rnd(8, seed=12)
     close(ops.depthwise_conv1d(dev(xc), dev(wc), dev(bc), 7), F.conv1d(xc, wc, bc, padding=7, groups=8), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ long batches (LDS-tiled fp32 GEMM)
+@pytest.mark.parametrize("M,N,K", [(496, 1024, 512), (700, 512, 1024), (1984, 1536, 512), (4464, 512, 512), (400, 1434, 512),
+                                   (6000, 1024, 512)])
+def test_linear_tiled_plain(M, N, K):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = ops.linear(dev(a), dev(w), dev(b))
+    close(y, F.linear(a.double(), w.double(), b.double()).float(), 3e-5, 3e-5)
+
+
+@pytest.mark.parametrize("B,T", [(8, 97), (40, 124)])       # 776 rows: 64-row tiles; 4960 rows: 128-row tiles
+def test_linear_tiled_epilogues(B, T):
+    M, N, K = B * T, 512, 512
+    a, w, b = rnd(M, K, seed=1), rnd(2 * N, K, seed=2, scale=K ** -0.5), rnd(2 * N, seed=3)
+    lens = torch.tensor(([T, 20, 1, T - 1, 50, T, 33, 64] * 5)[:B], dtype=torch.int32)
+    pad = (torch.arange(T).view(1, -1) >= lens.view(-1, 1)).reshape(M, 1)
+    res = rnd(M, N, seed=4)
+    lin = F.linear(a.double(), w.double(), b.double())
+    y = ops.linear(dev(a), dev(w[:N]), dev(b[:N]), act=_lib.ACT_SILU, alpha=0.5, resid=dev(res))
+    close(y, (res.double() + 0.5 * F.silu(lin[:, :N])).float(), 3e-5, 3e-5)
+    lin0 = F.linear(a.masked_fill(pad, 0.0).double(), w.double(), b.double())
+    y = ops.linear(dev(a), dev(w), dev(b), act=_lib.ACT_GLU, lens=dev(lens), rows_per_batch=T, mask_in=True)
+    close(y, (lin0[:, :N] * torch.sigmoid(lin0[:, N:])).float(), 3e-5, 3e-5)
+    y = ops.linear(dev(a), dev(w[:N]), dev(b[:N]), act=_lib.ACT_RELU, lens=dev(lens), rows_per_batch=T, mask_out=True)
+    close(y, F.relu(lin[:, :N]).masked_fill(pad, 0.0).float(), 3e-5, 3e-5)
+
+
+@pytest.mark.parametrize("M,N,mean,std", [(600, 1024, 0.0, 1.0), (1111, 1024, 1.5, 3.0), (5000, 1536, 0.0, 1.0)])
+def test_linear_tiled_folded_layernorm(M, N, mean, std):
+    from m3asr.plan import fold_layernorm
+    K, eps = 512, 1e-12
+    a = rnd(M, K, seed=1) * std + mean
+    w, b = rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ga, be = rnd(K, seed=4) * 0.2 + 1.0, rnd(K, seed=5, scale=0.1)
+    f = fold_layernorm(w, b, ga, be)
+    y = ops.linear(dev(a), dev(f["ln.weight"]), dev(f["ln.bias"]), ln_folded=(dev(f["ln.wsum"]), None, eps))
+    want = F.linear(F.layer_norm(a.double(), (K,), ga.double(), be.double(), eps), w.double(), b.double())
+    close(y, want.float(), 2e-4 * (1 + abs(mean)), 2e-4 * (1 + abs(mean)))
