@@ -72,18 +72,27 @@ struct m3_engine {
   const float* output_bias = nullptr;                                     // optional [V] added to the output (-log prior)
   const float* router_e_all = nullptr;   // [num_blocks * E][De]: embed half of every layer's router (fused route path)
 
-  // bound shape
-  int B = 0, T = 0, Tp = 0, S = 0;
-  const float* feat = nullptr; const int32_t* feat_len = nullptr; float* logits = nullptr;
-  void* ws = nullptr; size_t ws_bytes = 0;
-  float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
-  std::vector<Stage> stages;
-  std::unordered_map<std::string, Buf> buffers;
-  int n_kernels = 0;
-
-  // graph cache (one entry: last bound shape)
-  hipGraphExec_t graph_exec = nullptr;
-  bool graph_valid = false;
+  // state of the bound shape (buffers + stage list + captured graph); up to cfg.shape_cache more are parked, so a server
+  // that alternates between a few (B, T) buckets with static I/O buffers replays graphs instead of re-capturing them
+  struct Bound {
+    int B = 0, T = 0, Tp = 0, S = 0;
+    const float* feat = nullptr; const int32_t* feat_len = nullptr; float* logits = nullptr;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
+    std::vector<Stage> stages;
+    std::unordered_map<std::string, Buf> buffers;
+    int n_kernels = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false;
+    uint64_t last_use = 0;
+    bool matches(int b, int t, const float* f, const int32_t* fl, const float* lg, const void* w, size_t wb) const {
+      return !stages.empty() && B == b && T == t && feat == f && feat_len == fl && logits == lg && ws == w && ws_bytes == wb;
+    }
+  };
+  Bound cur;
+  std::vector<Bound> parked;
+  uint64_t use_clock = 0;
+  int n_captures = 0;                                      // graphs captured so far (observability / tests)
 };
 
 namespace {
@@ -259,16 +268,16 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
 
 // ------------------------------------------------------------------------------------------------
 static void add_stage(m3_engine* e, const std::string& name, int kernels, std::function<int(hipStream_t)> fn) {
-  e->stages.push_back(Stage{name, std::move(fn)});
-  e->n_kernels += kernels;
+  e->cur.stages.push_back(Stage{name, std::move(fn)});
+  e->cur.n_kernels += kernels;
 }
 
 // fp32_weights: the router GEMMs keep fp32 weights in every mode (a flipped top-1 is a discrete error)
 static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool fp32_weights = false) {
   p.w_bf16 = (!fp32_weights && e->cfg.weight_dtype == M3_BF16) ? 1 : 0;
   size_t need = 0;
-  if (gemm_f32_splitk_plan(p, &need) >= 2 && e->splitk_ws != nullptr && need <= e->splitk_bytes) {
-    float* ws = e->splitk_ws; const size_t wsb = e->splitk_bytes;
+  if (gemm_f32_splitk_plan(p, &need) >= 2 && e->cur.splitk_ws != nullptr && need <= e->cur.splitk_bytes) {
+    float* ws = e->cur.splitk_ws; const size_t wsb = e->cur.splitk_bytes;
     add_stage(e, name, 2, [p, ws, wsb](hipStream_t s) { return launch_gemm_f32_splitk(p, ws, wsb, s); });
     return;
   }
@@ -277,9 +286,9 @@ static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool f
 
 static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w, int D, const Plan& pl, float* xout) {
   const m3_engine_config& c = e->cfg;
-  const int B = e->B, T = e->T;
+  const int B = e->cur.B, T = e->cur.T;
   const int T1 = (T - 3) / 2 + 1, F1 = (c.input_dim - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1, T2 = (T1 - 3) / 2 + 1;
-  const float* feat = e->feat;
+  const float* feat = e->cur.feat;
   float* c1 = pl.c1; float* c2 = pl.c2;
   const int idim = c.input_dim;
   const float* cm = e->cmvn_mean; const float* ci = e->cmvn_istd;
@@ -300,7 +309,7 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
 static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, int D, int F, int H, int K, bool cnn_ln,
                         bool moe, int layer, int tap_index, const Plan& pl) {
   const m3_engine_config& c = e->cfg;
-  const int B = e->B, Tp = e->Tp, S = e->S;
+  const int B = e->cur.B, Tp = e->cur.Tp, S = e->cur.S;
   float* x = pl.x;
   const int32_t* lens = pl.lens;
   const float eps = 1e-12f;  // all block LayerNorms (fmoe_transformer.py:54-65)
@@ -445,10 +454,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
     });
     const std::string b = pfx.substr(0, pfx.size() - 1);
-    e->buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
-    e->buffers[b + ".gate_value"] = Buf{gval, (size_t)S * 4};
-    e->buffers[b + ".mapping"] = Buf{mw.mapping, (size_t)S * 4};
-    e->buffers[b + ".acc_histogram"] = Buf{mw.acc, (size_t)(E + 1) * 4};
+    e->cur.buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
+    e->cur.buffers[b + ".gate_value"] = Buf{gval, (size_t)S * 4};
+    e->cur.buffers[b + ".mapping"] = Buf{mw.mapping, (size_t)S * 4};
+    e->cur.buffers[b + ".acc_histogram"] = Buf{mw.acc, (size_t)(E + 1) * 4};
   }
   if (c.debug_taps) {
     float* tap = pl.taps + (size_t)tap_index * S * D;
@@ -456,7 +465,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       M3_CHECK_HIP(hipMemcpyAsync(tap, x, (size_t)S * D * sizeof(float), hipMemcpyDeviceToDevice, s));
       return 0;
     });
-    e->buffers[pfx.substr(0, pfx.size() - 1) + ".out"] = Buf{tap, (size_t)S * D * 4};
+    e->cur.buffers[pfx.substr(0, pfx.size() - 1) + ".out"] = Buf{tap, (size_t)S * D * 4};
   }
 }
 
@@ -538,7 +547,9 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
 
 void m3_engine_destroy(m3_engine* engine) {
   if (!engine) return;
-  if (engine->graph_exec) hipGraphExecDestroy(engine->graph_exec);
+  if (engine->cur.graph_exec) (void)hipGraphExecDestroy(engine->cur.graph_exec);
+  for (auto& b : engine->parked)
+    if (b.graph_exec) (void)hipGraphExecDestroy(b.graph_exec);
   delete engine;
 }
 
@@ -562,12 +573,41 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   const Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
-  e->B = B; e->T = T; e->Tp = Tp; e->S = B * Tp;
-  e->feat = feat; e->feat_len = feat_len; e->logits = logits; e->ws = workspace; e->ws_bytes = workspace_bytes;
-  e->stages.clear(); e->buffers.clear(); e->n_kernels = 0; e->graph_valid = false;
-  e->splitk_ws = pl.splitk; e->splitk_bytes = pl.splitk_bytes;
+  // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----
+  if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
+    e->cur.last_use = ++e->use_clock;
+    return (int)e->cur.stages.size();
+  }
+  const int capacity = c.shape_cache > 0 ? c.shape_cache : (c.shape_cache < 0 ? 0 : 7);
+  if (!e->cur.stages.empty()) {
+    if (capacity > 0) {
+      if ((int)e->parked.size() >= capacity) {           // evict the least recently used binding
+        size_t lru = 0;
+        for (size_t i = 1; i < e->parked.size(); ++i)
+          if (e->parked[i].last_use < e->parked[lru].last_use) lru = i;
+        if (e->parked[lru].graph_exec) (void)hipGraphExecDestroy(e->parked[lru].graph_exec);
+        e->parked.erase(e->parked.begin() + lru);
+      }
+      e->parked.push_back(std::move(e->cur));
+    } else if (e->cur.graph_exec) {
+      (void)hipGraphExecDestroy(e->cur.graph_exec);
+    }
+    e->cur = m3_engine::Bound();
+  }
+  for (size_t i = 0; i < e->parked.size(); ++i)
+    if (e->parked[i].matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
+      e->cur = std::move(e->parked[i]);
+      e->parked.erase(e->parked.begin() + i);
+      e->cur.last_use = ++e->use_clock;
+      return (int)e->cur.stages.size();
+    }
+  e->cur.last_use = ++e->use_clock;
+  e->cur.B = B; e->cur.T = T; e->cur.Tp = Tp; e->cur.S = B * Tp;
+  e->cur.feat = feat; e->cur.feat_len = feat_len; e->cur.logits = logits; e->cur.ws = workspace; e->cur.ws_bytes = workspace_bytes;
+  e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false;
+  e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
-  const int S = e->S, D = c.attention_dim, De = c.embed_dim;
+  const int S = e->cur.S, D = c.attention_dim, De = c.embed_dim;
 
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
   {
@@ -624,35 +664,36 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
       add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(logits, ob, logits, (size_t)S, V, s); });
     }   // without log-softmax a prior is folded into out_linear's bias when the plan is packed (plan.py)
   }
-  e->buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
-  e->buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
-  e->buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
-  e->buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
-  e->buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
+  e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
+  e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
+  e->cur.buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
+  e->cur.buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
+  e->cur.buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 
-  return (int)e->stages.size();
+  return (int)e->cur.stages.size();
 }
 
-int m3_engine_num_stages(const m3_engine* engine) { return engine ? (int)engine->stages.size() : 0; }
+int m3_engine_num_stages(const m3_engine* engine) { return engine ? (int)engine->cur.stages.size() : 0; }
 const char* m3_engine_stage_name(const m3_engine* engine, int index) {
-  if (!engine || index < 0 || index >= (int)engine->stages.size()) return nullptr;
-  return engine->stages[index].name.c_str();
+  if (!engine || index < 0 || index >= (int)engine->cur.stages.size()) return nullptr;
+  return engine->cur.stages[index].name.c_str();
 }
-int m3_engine_num_kernels(const m3_engine* engine) { return engine ? engine->n_kernels : 0; }
+int m3_engine_num_captures(const m3_engine* engine) { return engine ? engine->n_captures : 0; }
+int m3_engine_num_kernels(const m3_engine* engine) { return engine ? engine->cur.n_kernels : 0; }
 
 int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream stream) {
-  M3_REQUIRE(engine && !engine->stages.empty(), "engine_run: engine not prepared");
-  M3_REQUIRE(first_stage >= 0 && last_stage <= (int)engine->stages.size() && first_stage <= last_stage,
+  M3_REQUIRE(engine && !engine->cur.stages.empty(), "engine_run: engine not prepared");
+  M3_REQUIRE(first_stage >= 0 && last_stage <= (int)engine->cur.stages.size() && first_stage <= last_stage,
              "engine_run: bad stage range [%d,%d)", first_stage, last_stage);
   for (int i = first_stage; i < last_stage; ++i)
-    if (int rc = engine->stages[i].run((hipStream_t)stream)) return rc;
+    if (int rc = engine->cur.stages[i].run((hipStream_t)stream)) return rc;
   return 0;
 }
 
 int m3_engine_buffer(const m3_engine* engine, const char* name, void** ptr, size_t* bytes) {
   M3_REQUIRE(engine && name && ptr && bytes, "engine_buffer: null argument");
-  auto it = engine->buffers.find(name);
-  M3_REQUIRE(it != engine->buffers.end(), "engine_buffer: no buffer named '%s' for the bound shape", name);
+  auto it = engine->cur.buffers.find(name);
+  M3_REQUIRE(it != engine->cur.buffers.end(), "engine_buffer: no buffer named '%s' for the bound shape", name);
   *ptr = it->second.ptr;
   *bytes = it->second.bytes;
   return 0;
@@ -662,33 +703,33 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
                       void* workspace, size_t workspace_bytes, int use_graph, m3_stream stream_) {
   M3_REQUIRE(e != nullptr, "engine_forward: null engine");
   hipStream_t stream = (hipStream_t)stream_;
-  const bool rebound = e->stages.empty() || e->B != B || e->T != T || e->feat != feat || e->feat_len != feat_len ||
-                       e->logits != logits || e->ws != workspace || e->ws_bytes != workspace_bytes;
-  if (rebound) {
+  if (!e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
     int rc = m3_engine_prepare(e, feat, feat_len, B, T, logits, workspace, workspace_bytes);
     if (rc < 0) return rc;
   }
-  if (!use_graph) return m3_engine_run(e, 0, (int)e->stages.size(), stream_);
-  if (!e->graph_valid) {
+  e->cur.last_use = ++e->use_clock;
+  if (!use_graph) return m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
+  if (!e->cur.graph_valid) {
     M3_REQUIRE(stream != nullptr, "engine_forward: graph capture needs a non-default stream");
-    if (e->graph_exec) {
-      hipGraphExecDestroy(e->graph_exec);
-      e->graph_exec = nullptr;
+    if (e->cur.graph_exec) {
+      hipGraphExecDestroy(e->cur.graph_exec);
+      e->cur.graph_exec = nullptr;
     }
     hipGraph_t graph = nullptr;
     M3_CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    int rc = m3_engine_run(e, 0, (int)e->stages.size(), stream_);
+    int rc = m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
     hipError_t ce = hipStreamEndCapture(stream, &graph);
     if (rc) {
       if (graph) hipGraphDestroy(graph);
       return rc;
     }
     M3_CHECK_HIP(ce);
-    M3_CHECK_HIP(hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0));
+    M3_CHECK_HIP(hipGraphInstantiate(&e->cur.graph_exec, graph, nullptr, nullptr, 0));
     M3_CHECK_HIP(hipGraphDestroy(graph));
-    e->graph_valid = true;
+    e->cur.graph_valid = true;
+    ++e->n_captures;
   }
-  M3_CHECK_HIP(hipGraphLaunch(e->graph_exec, stream));
+  M3_CHECK_HIP(hipGraphLaunch(e->cur.graph_exec, stream));
   return 0;
 }
 

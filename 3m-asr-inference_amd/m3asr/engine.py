@@ -67,7 +67,8 @@ class Engine:
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())
         self.stream = torch.cuda.Stream(device=self.device)
-        self._ws = None
+        self._ws = {}          # (B, T) -> workspace; kept for the life of the engine: the native shape cache may hold a
+        self._static = {}      # parked binding whose workspace contains the folded positional projection
         self._bound = None
 
     @classmethod
@@ -93,10 +94,10 @@ class Engine:
         return self.lib.m3_engine_workspace_size(self.handle, B, T)
 
     def _workspace(self, B, T):
-        need = self.workspace_size(B, T)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        ws = self._ws.get((B, T))
+        if ws is None:
+            ws = self._ws[(B, T)] = torch.empty(self.workspace_size(B, T), dtype=torch.uint8, device=self.device)
+        return ws
 
     def bind(self, feat, feat_len, logits=None):
         """Bind device buffers (feat (B,T,idim) f32, feat_len (1,B)/(B,) i32); returns logits tensor."""
@@ -127,6 +128,30 @@ class Engine:
                                          ws.data_ptr(), ws.numel(), int(use_graph), C.c_void_p(st.cuda_stream)),
               "m3_engine_forward")
         return logits
+
+    def infer(self, feat, feat_len):
+        """Serving entry point: static per-shape device buffers + graph replay.  feat (B,T,idim) / feat_len (B,) or (1,B) on
+        any device are copied into this shape's input buffers, the shape's hipGraph is replayed on the engine stream
+        (captured on first use; the native engine keeps the stage lists and graphs of the last few shapes, so alternating
+        between length buckets re-captures nothing) and the shape's logits buffer is returned -- valid until the next
+        infer() of the same shape."""
+        B, T = int(feat.shape[0]), int(feat.shape[1])
+        st = self._static.get((B, T))
+        if st is None:
+            st = self._static[(B, T)] = (
+                torch.empty(B, T, self.cfg.input_dim, dtype=torch.float32, device=self.device),
+                torch.empty(1, B, dtype=torch.int32, device=self.device),
+                torch.empty(self.output_shape(B, T), dtype=torch.float32, device=self.device))
+        f, l, out = st
+        with torch.cuda.stream(self.stream):
+            f.copy_(feat, non_blocking=True)
+            l.copy_(feat_len.reshape(1, B).to(torch.int32), non_blocking=True)
+        self.forward(f, l, out, use_graph=True)
+        self.stream.synchronize()
+        return out
+
+    def num_captures(self):
+        return self.lib.m3_engine_num_captures(self.handle)
 
     def __call__(self, feat, feat_len):
         """Synchronous convenience: waits for prior work on the current stream, runs, syncs."""

@@ -244,6 +244,9 @@ typedef struct m3_engine_config {
   int32_t fuse_route;            /* 1 = router + SoftmaxTopK + ScatterMapping in one launch per layer (S <= 256, 1 rank);
                                   * 2 = split route: embed half of all routers in one GEMM, x half with folded LayerNorm,
                                   *     norm_ff applied by the expert kernel (1 rank, fp32) */
+  int32_t shape_cache;           /* bound (shape, buffers) sets kept besides the current one, each with its stage list and
+                                  * captured hipGraph (LRU): 0 = default 7, -1 = none.  A parked binding's workspace must be
+                                  * left untouched by the caller (it holds the folded positional projection). */
   int32_t weight_dtype;          /* M3_F32 / M3_BF16: storage of the GEMM weights (linear / point-wise conv /
                                   * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32 */
 } m3_engine_config;
@@ -273,6 +276,7 @@ int m3_engine_forward(m3_engine* engine, const float* feat, const int32_t* feat_
 int m3_engine_prepare(m3_engine* engine, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
                       void* workspace, size_t workspace_bytes);
 int m3_engine_num_stages(const m3_engine* engine);
+int m3_engine_num_captures(const m3_engine* engine); /* hipGraphs captured so far (a cache hit replays, it does not capture) */
 const char* m3_engine_stage_name(const m3_engine* engine, int index);
 int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream stream);
 /* Device address (inside the bound workspace) and size of a named intermediate of the prepared shape:
