@@ -107,4 +107,18 @@ __device__ __forceinline__ f32x4 mfma16h(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- fp8 (OCP e4m3) weights: dequantised to bf16 on their way to the MFMA (every e4m3 value is exact in bf16) ----
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 ldg16b(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// 8 consecutive fp8 (two dwords) -> bf16x8, element order preserved
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+  bf16x8 r;
+  r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)b[0]; r[3] = (bf16_t)b[1];
+  r[4] = (bf16_t)c[0]; r[5] = (bf16_t)c[1]; r[6] = (bf16_t)d[0]; r[7] = (bf16_t)d[1];
+  return r;
+}
+
 }  // namespace m3

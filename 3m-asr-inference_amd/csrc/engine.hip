@@ -44,6 +44,7 @@ struct BlockW {
   Lin router;                       // w: [E_total][D + De]  (unfused route path)
   Lin router_x;                     // w: [E][D] x-half with norm_ff folded (+ wsum, bias)  (fused route path)
   const float *ew1 = nullptr, *eb1 = nullptr, *ew2 = nullptr, *eb2 = nullptr;
+  const float *es1 = nullptr, *es2 = nullptr;   // fp8 experts: per-row scales [E][F], [E][D]
 };
 
 struct SubW { const float* c1w; const float* c1b; const float* c2w; const float* c2b; Lin out; };
@@ -120,7 +121,10 @@ bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const fl
 
 #define GET(dst, name, numel) \
   do { if (!lookup(e, (name), (numel), &(dst))) return false; } while (0)
+// dense GEMM weights: fp32, or bf16 in both 16-bit and fp8 modes; expert weights follow weight_dtype itself
 #define GETW(dst, name, numel) \
+  do { if (!lookup(e, (name), (numel), &(dst), e->cfg.weight_dtype == M3_F32 ? M3_F32 : M3_BF16)) return false; } while (0)
+#define GETE(dst, name, numel) \
   do { if (!lookup(e, (name), (numel), &(dst), e->cfg.weight_dtype)) return false; } while (0)
 
 bool load_norm(const m3_engine* e, const std::string& p, int d, Norm* n) {
@@ -175,9 +179,13 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
     if (c.router_with_bias) GET(b->router.b, p + "feed_forward.router_bias", Etot);
     if (c.fuse_route && !load_lin_ln(e, p + "feed_forward.router_x.", Etot, D, false, &b->router_x, true)) return false;
     const int64_t E = c.num_experts;
-    GETW(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
+    GETE(b->ew1, p + "feed_forward.experts.w_1.weight", E * F * D);
+    if (c.weight_dtype == M3_FP8) {
+      GET(b->es1, p + "feed_forward.experts.w_1.scale", E * F);
+      GET(b->es2, p + "feed_forward.experts.w_2.scale", E * D);
+    }
     GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
-    GETW(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
+    GETE(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
     GET(b->eb2, p + "feed_forward.experts.w_2.bias", E * D);
   }
   return true;
@@ -193,6 +201,7 @@ bool load_sub(const m3_engine* e, const std::string& p, int D, int idim, SubW* s
 }
 #undef GET
 #undef GETW
+#undef GETE
 
 inline int sub_len(int t) { return ((t - 3) / 2 + 1 - 3) / 2 + 1; }
 
@@ -274,7 +283,7 @@ static void add_stage(m3_engine* e, const std::string& name, int kernels, std::f
 
 // fp32_weights: the router GEMMs keep fp32 weights in every mode (a flipped top-1 is a discrete error)
 static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool fp32_weights = false) {
-  p.w_bf16 = (!fp32_weights && e->cfg.weight_dtype == M3_BF16) ? 1 : 0;
+  p.w_bf16 = (!fp32_weights && e->cfg.weight_dtype != M3_F32) ? 1 : 0;
   size_t need = 0;
   if (gemm_f32_splitk_plan(p, &need) >= 2 && e->cur.splitk_ws != nullptr && need <= e->cur.splitk_bytes) {
     float* ws = e->cur.splitk_ws; const size_t wsb = e->cur.splitk_bytes;
@@ -439,15 +448,17 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
       });
     }
-    const bool e16 = c.weight_dtype == M3_BF16;
+    const bool e16 = c.weight_dtype != M3_F32, e8 = c.weight_dtype == M3_FP8;
+    const float *es1 = w.es1, *es2 = w.es2;
     const bool etiled = e16 ? expert_ffn_bf16_tiled(S, E, D, F) : expert_ffn_f32_tiled(S, E, D, F);
     add_stage(e, pfx + "moe_local.expert", etiled ? 2 : 1, [=](hipStream_t s) {
+      if (e8) return launch_expert_ffn_w8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, mw.slab, s);
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     });
     }
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
-    const bool e16c = c.weight_dtype == M3_BF16;
+    const bool e16c = c.weight_dtype != M3_F32;
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
@@ -490,8 +501,11 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   if (c.attention_dim % 16 || c.embed_dim % 16 || c.hidden_units % 64 || c.embed_linear_units % 16)
     return fail("engine_create: dims must be multiples of 16 (hidden_units of 64)");
   if (c.embed_dim != c.attention_dim) return fail("engine_create: embed_dim != attention_dim is not supported");
-  if (c.weight_dtype != M3_F32 && c.weight_dtype != M3_BF16) return fail("engine_create: weight_dtype must be f32 or bf16");
-  if (c.weight_dtype == M3_BF16) {
+  if (c.weight_dtype != M3_F32 && c.weight_dtype != M3_BF16 && c.weight_dtype != M3_FP8)
+    return fail("engine_create: weight_dtype must be f32, bf16 or fp8");
+  if (c.weight_dtype == M3_FP8 && (c.attention_dim % 64 || c.hidden_units % 64))
+    return fail("engine_create: fp8 experts need attention_dim and hidden_units that are multiples of 64");
+  if (c.weight_dtype != M3_F32) {
     if (c.fuse_route) return fail("engine_create: fuse_route is fp32-only");
     if (c.attention_dim % 32 || c.hidden_units % 64 || c.embed_linear_units % 32)
       return fail("engine_create: bf16 weights need dims that are multiples of 32");
@@ -529,7 +543,9 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
     e->pe = (const float*)it->second.data;
     e->pe_rows = it->second.numel / D;
   }
-  if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all, c.weight_dtype)) return fail(nullptr);
+  if (!lookup(e, "pos_all.weight", (int64_t)(c.embed_blocks + c.num_blocks) * D * D, &e->pos_all,
+              c.weight_dtype == M3_F32 ? M3_F32 : M3_BF16))
+    return fail(nullptr);
   if (c.fuse_route && !lookup(e, "router_e_all.weight", (int64_t)c.num_blocks * c.num_experts * De, &e->router_e_all))
     return fail(nullptr);
   e->eblocks.resize(c.embed_blocks);
@@ -568,6 +584,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
              (long long)e->pe_rows);  // rel_positional_encoding_plugin.cpp:139-142
   if (int rc = init_expert_ffn_kernels()) return rc;
   if (int rc = init_expert_ffn_bf16_kernels()) return rc;
+  if (int rc = init_expert_ffn_w8_kernels()) return rc;
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
@@ -621,7 +638,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams pp;
     pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
     if (c.fold_pos_proj) {
-      pp.w_bf16 = c.weight_dtype == M3_BF16;
+      pp.w_bf16 = c.weight_dtype != M3_F32;
       if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
       M3_CHECK_HIP(hipStreamSynchronize(nullptr));
     } else {

@@ -35,15 +35,19 @@ constexpr int tiled_lds_bytes(int BM, int BN, int BK) {
 //   row tiles are cut per expert from acc_hist (p.grp_acc), W / bias are that expert's;
 //   1: A rows are gathered through pos (fused local_scatter), fp32 -> H = SiLU(. + b1) written as bf16 in sorted order;
 //   2: A = H (bf16, no conversion while staging), W2 in the plan's slice-major layout or [D][F], fp32 rows out.
-template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN, int GRP>
+// W8 (grouped forms only): W holds fp8 e4m3 with a per-output-row scale (p.w_scale); the staging threads dequantise it to
+// bf16 on the way into LDS (exact) and the scale is applied to the accumulator in the epilogue.
+template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN, int GRP, bool W8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmParams p) {
   static_assert(GRP == 0 || (!GLU && !CONV && !LN), "grouped form is a plain GEMM");
+  static_assert(!W8 || GRP != 0, "fp8 weights: grouped expert GEMMs only");
   constexpr int T_LD = TBK + 8;                     // bf16 elements per LDS row (144 / 272 B: conflict-free 16-B reads)
   constexpr int C_LD = TBN + 4;                     // fp32 elements per row of the epilogue image
   constexpr int MT = TBM / 32, NT = TBN / 32;       // 16x16 MFMA tiles per wave (wave tile = TBM/2 x TBN/2)
   constexpr bool A16 = GRP == 2;                    // A operand already bf16 (16-B chunks of 8 elements)
   constexpr int CA = A16 ? TBK / 8 : TBK / 4, RA = 256 / CA, JA = TBM / RA;   // A staging: chunks per row, rows per pass, passes
-  constexpr int CB = TBK / 8, RB = 256 / CB, JB = TBN / RB;   // W staging: 16-B chunks per row, rows per pass, passes
+  constexpr int WCE = W8 ? 16 : 8, WSZ = W8 ? 1 : 2;          // W elements per 16-B chunk, bytes per element
+  constexpr int CB = TBK / WCE, RB = 256 / CB, JB = TBN / RB;  // W staging: 16-B chunks per row, rows per pass, passes
   extern __shared__ __attribute__((aligned(16))) unsigned char tiled_lds[];
   bf16_t* As = reinterpret_cast<bf16_t*>(tiled_lds);                // [2][TBM][T_LD]
   bf16_t* Bs = As + 2 * TBM * T_LD;                                 // [2][TBN][T_LD]
@@ -128,23 +132,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   }
   // W: thread t brings 16-B chunk (t % CB) of tile rows (t / CB) + RB j
   const int bc = tid % CB, br0 = tid / CB;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + (GRP ? (size_t)expert * p.N * p.K : 0);
-  const bf16_t* bptr[JB];
+  const unsigned char* W = reinterpret_cast<const unsigned char*>(p.W) + (GRP ? (size_t)expert * p.N * p.K * WSZ : 0);
+  const unsigned char* bptr[JB];
   int brow_n[JB];
 #pragma unroll
   for (int j = 0; j < JB; ++j) {
     const int tr = br0 + RB * j;
     const int n = GLU ? (tr / (TBN / 2)) * Nout + min(n0 + (tr % (TBN / 2)), Nout - 1) : min(n0 + tr, p.N - 1);
     brow_n[j] = n;
-    bptr[j] = W + (size_t)n * p.K + 8 * bc;
+    bptr[j] = W + ((size_t)n * p.K + WCE * bc) * WSZ;
   }
-  // slice-major W (plan's expert w_2: [K/64][N][64]): the 8-element chunk kc of row n sits at ((kc>>3)*N + n)*64 + 8*(kc&7)
-  auto w_ptr = [&](int j, int s) -> const bf16_t* {
+  // slice-major W (plan's expert w_2: [K/64][N][64]): element k of row n sits at ((k>>6)*N + n)*64 + (k&63)
+  auto w_ptr = [&](int j, int s) -> const unsigned char* {
     if (GRP == 2 && p.w_sliced) {
-      const int kc = s * CB + bc;
-      return W + ((size_t)(kc >> 3) * p.N + brow_n[j]) * 64 + 8 * (kc & 7);
+      const int k0 = (s * CB + bc) * WCE;
+      return W + (((size_t)(k0 >> 6) * p.N + brow_n[j]) * 64 + (k0 & 63)) * WSZ;
     }
-    return bptr[j] + s * TBK;
+    return bptr[j] + (size_t)s * TBK * WSZ;
   };
   auto a_offset = [&](int k) -> int {
     if (CONV) {
@@ -166,18 +170,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
 
   const int nsteps = p.K / TBK;
   f32x4 areg[JA];                                   // A16: the 16 bytes are 8 bf16, carried as they are
-  bf16x8 breg[JB];
+  u32x4 breg[JB];                                   // 16 bytes of W: 8 bf16, or 16 fp8 (W8)
   auto load_tiles = [&](int s) {
     const int ko = A16 ? (s * TBK) / 2 : a_offset(s * TBK);       // in floats
 #pragma unroll
     for (int j = 0; j < JA; ++j) areg[j] = ldg4(aptr[j] + ko);
 #pragma unroll
-    for (int j = 0; j < JB; ++j) breg[j] = ldg8h(w_ptr(j, s));
+    for (int j = 0; j < JB; ++j) breg[j] = ldg16b(w_ptr(j, s));
   };
   // `on` = 0 for the redundant store after the last k-step (the store stays unconditional, see the header)
   auto store_tiles = [&](int buf, float on) {
     bf16_t* a_dst = As + buf * (TBM * T_LD) + ar0 * T_LD + (A16 ? 8 : 4) * ac;
-    bf16_t* b_dst = Bs + buf * (TBN * T_LD) + br0 * T_LD + 8 * bc;
+    bf16_t* b_dst = Bs + buf * (TBN * T_LD) + br0 * T_LD + WCE * bc;
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
       const f32x4 v = areg[j];
@@ -195,7 +199,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       *reinterpret_cast<bf16x4*>(a_dst + RA * j * T_LD) = h;
     }
 #pragma unroll
-    for (int j = 0; j < JB; ++j) *reinterpret_cast<bf16x8*>(b_dst + RB * j * T_LD) = breg[j];
+    for (int j = 0; j < JB; ++j) {
+      if (W8) {
+        *reinterpret_cast<bf16x8*>(b_dst + RB * j * T_LD) = fp8x8_to_bf16(breg[j][0], breg[j][1]);
+        *reinterpret_cast<bf16x8*>(b_dst + RB * j * T_LD + 8) = fp8x8_to_bf16(breg[j][2], breg[j][3]);
+      } else {
+        *reinterpret_cast<u32x4*>(b_dst + RB * j * T_LD) = breg[j];
+      }
+    }
   };
 
   load_tiles(0);
@@ -252,10 +263,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   constexpr int RPI = 64 / LPR;                     // rows per wave iteration (2, GLU 4)
   const int c4 = 4 * (lane % LPR);                  // first of this lane's 4 columns inside the tile
   const int n = n0 + c4;
-  float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4];
+  float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4], wsc[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int ne = min(n + e, Nout - 1);
+    wsc[e] = W8 ? p.w_scale[(size_t)expert * p.N + ne] : 1.f;
     bias0[e] = p.bias ? p.bias[(GRP ? (size_t)expert * p.N : 0) + ne] : 0.f;
     bias1[e] = (GLU && p.bias) ? p.bias[ne + Nout] : 0.f;
     wsum0[e] = LN ? p.ln_wsum[ne] : 0.f;
@@ -293,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float y0 = v0[e], y1 = v1[e];
+      if (W8) y0 *= wsc[e];
       if (LN) {
         if (p.mask_in && pad) {
           y0 = -wbeta0[e];
@@ -344,6 +357,11 @@ int init_gemm_bf16_tiled_kernels() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(BM_, BN_, BK_)))
   M3_GRP_ATTR(128, 128, 64, 1); M3_GRP_ATTR(128, 128, 64, 2); M3_GRP_ATTR(64, 64, 128, 1); M3_GRP_ATTR(64, 64, 128, 2);
 #undef M3_GRP_ATTR
+#define M3_GRP8_ATTR(BM_, BN_, BK_, P_)                                                                                 \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, P_, true>,  \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(BM_, BN_, BK_)))
+  M3_GRP8_ATTR(128, 128, 64, 1); M3_GRP8_ATTR(128, 128, 64, 2); M3_GRP8_ATTR(64, 64, 128, 1); M3_GRP8_ATTR(64, 64, 128, 2);
+#undef M3_GRP8_ATTR
   done = true;
   return 0;
 }
@@ -412,6 +430,38 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
   } while (0)
   if (big) M3_GRP_LAUNCH(128, 128, 64); else M3_GRP_LAUNCH(64, 64, 128);
 #undef M3_GRP_LAUNCH
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same with fp8 expert weights + per-row scales (W8A16, see moe_expert_fp8.hip)
+int launch_expert_ffn_w8_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
+                               int F, const void* w1, const float* s1, const float* b1, const void* w2, const float* s2,
+                               int w2_sliced, void* hbuf, float* ybuf, hipStream_t stream) {
+  M3_REQUIRE((D & 127) == 0 && (F & 127) == 0, "expert_ffn tiled: idim=%d / hidden=%d must be multiples of 128", D, F);
+  if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
+  const bool big = S / E >= 192;
+  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+  const int m_slots = cdiv(cdiv(S, bm) + E, 8) * 8;
+  GemmParams g1;
+  g1.A = x; g1.lda = ldx; g1.W = (const float*)w1; g1.w_scale = s1; g1.bias = b1; g1.Y = (float*)hbuf; g1.ldy = F;
+  g1.M = S; g1.N = F; g1.K = D; g1.act = ACT_SILU;
+  g1.grp_acc = acc_hist; g1.grp_E = E; g1.grp_pos = pos;
+  g1.n_tiles = cdiv(F, bn); g1.m_tiles = m_slots;
+  GemmParams g2;
+  g2.A = (const float*)hbuf; g2.lda = F; g2.W = (const float*)w2; g2.w_scale = s2; g2.Y = ybuf; g2.ldy = D;
+  g2.M = S; g2.N = D; g2.K = F; g2.w_sliced = w2_sliced;
+  g2.grp_acc = acc_hist; g2.grp_E = E;
+  g2.n_tiles = cdiv(D, bn); g2.m_tiles = m_slots;
+#define M3_GRP8_LAUNCH(BM_, BN_, BK_)                                                                                      \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, 1, true>), dim3(m_slots * g1.n_tiles), \
+                       dim3(256), tiled_lds_bytes(BM_, BN_, BK_), stream, g1);                                             \
+    hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, 2, true>), dim3(m_slots * g2.n_tiles), \
+                       dim3(256), tiled_lds_bytes(BM_, BN_, BK_), stream, g2);                                             \
+  } while (0)
+  if (big) M3_GRP8_LAUNCH(128, 128, 64); else M3_GRP8_LAUNCH(64, 64, 128);
+#undef M3_GRP8_LAUNCH
   M3_LAUNCH_CHECK();
   return 0;
 }

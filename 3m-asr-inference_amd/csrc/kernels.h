@@ -34,6 +34,7 @@ struct GemmParams {
   const float* resid = nullptr; int ldr = 0;
   // grouped (per-expert) form of the tiled bf16 kernel: row tiles cut from acc_hist, optional row gather, slice-major W
   const int32_t* grp_acc = nullptr; int grp_E = 0; const int32_t* grp_pos = nullptr; int w_sliced = 0;
+  const float* w_scale = nullptr;                         // fp8 weights (grouped forms): per-output-row scale [E][N]
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
@@ -82,6 +83,11 @@ int init_expert_ffn_bf16_kernels();
 int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                             int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* slab,
                             hipStream_t stream);
+// fp8 (e4m3) expert weights + per-row scales, dequantised to bf16 at the MFMA input (moe_expert_fp8.hip); same result layout as bf16
+int init_expert_ffn_w8_kernels();
+int launch_expert_ffn_w8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
+                         const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
+                         float* slab, hipStream_t stream);
 // which form launch_expert_ffn_bf16w takes for this shape, and where / in how many slabs its result rows are
 bool expert_ffn_bf16_tiled(int S, int E, int D, int F);
 float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F);

@@ -51,7 +51,7 @@ class WeightEntry(C.Structure):  # m3_weight_entry
 
 
 FIELD_FLOAT32, FIELD_INT32 = 1, 5
-F32, F16, I8, I32, BF16 = 0, 1, 2, 3, 4
+F32, F16, I8, I32, BF16, FP8 = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GLU, ACT_SIGMOID, ACT_LOG = 0, 1, 2, 3, 4, 5
 OP_SUM, OP_PROD = 0, 1
 
@@ -86,6 +86,8 @@ SIGNATURES = {
                                _vp, _sz, _vp]),
     "m3_moe_expert_ffn_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                     _vp, _sz, _vp]),
+    "m3_moe_expert_ffn_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
+                                   _vp, _sz, _vp]),
     "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "m3_linear": (_i, [_P(LinearDesc), _vp]),

@@ -34,7 +34,8 @@ class EncoderConfig:
     ep_rank: int = 0
     max_len: int = 5000            # positional_encoding.py:31
     # storage of the GEMM weights: "f32" (exact fp32 MFMA) or "bf16" (bf16 MFMA, fp32 accumulate; activations stay
-    # fp32) = the reference's --fp16 / plugin_data_type 1 (builder.py:160, builder_helper.py:47-57)
+    # fp32) = the reference's --fp16 / plugin_data_type 1 (builder.py:160, builder_helper.py:47-57); "fp8" = bf16 dense
+    # weights + e4m3 expert weights with per-row scales, dequantised to bf16 at the MFMA input (the --int8 slot of the reference)
     weight_dtype: str = "f32"
     log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
 

@@ -15,7 +15,7 @@ from .config import EncoderConfig, subsampled_len
 from .plan import pack_weights
 
 
-_TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32}
+_TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32, torch.float8_e4m3fn: _lib.FP8}
 
 
 def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False):
@@ -32,7 +32,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
     ec.fold_pos_proj, ec.debug_taps, ec.fuse_route = int(fold_pos_proj), int(debug_taps), int(fuse_route)
     ec.log_softmax_out = int(cfg.log_softmax_out)
-    ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16}[cfg.weight_dtype]
+    ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "fp8": _lib.FP8}[cfg.weight_dtype]
     return ec
 
 

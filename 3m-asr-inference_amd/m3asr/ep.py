@@ -51,7 +51,8 @@ class HipBackend:
         return self.ops.moe_local_scatter(x, mapping, n_rows)
 
     def expert_ffn(self, rows, gate_local, w):
-        return self.ops.moe_expert_ffn(rows, gate_local, w["w1"], w["b1"], w["w2"], w["b2"])
+        return self.ops.moe_expert_ffn(rows, gate_local, w["w1"], w["b1"], w["w2"], w["b2"],
+                                       w1_scale=w.get("s1"), w2_scale=w.get("s2"))
 
     def combine(self, rows_sorted, mapping, gate_value, resid, alpha, ln, out=None):
         return self.ops.moe_combine(rows_sorted, mapping, gate_value, resid, alpha, ln, out=out)
@@ -122,8 +123,11 @@ class ExpertParallelEncoder:
             # the plan keeps w_2 slice-major [E, F/S, D, S] for the fused engine; the C-ABI op takes the reference
             # layout [E, D, F] -> undo once at set-up
             w2 = w[p + "feed_forward.experts.w_2.weight_sliced"].permute(0, 2, 1, 3).reshape(E, D, F).contiguous()
-            self.layers.append({"w": {"w1": w[p + "feed_forward.experts.w_1.weight"], "b1": w[p + "feed_forward.experts.w_1.bias"],
-                                      "w2": w2, "b2": w[p + "feed_forward.experts.w_2.bias"]},
+            wd = {"w1": w[p + "feed_forward.experts.w_1.weight"], "b1": w[p + "feed_forward.experts.w_1.bias"],
+                  "w2": w2, "b2": w[p + "feed_forward.experts.w_2.bias"]}
+            if (p + "feed_forward.experts.w_1.scale") in w:        # fp8 experts: per-row scales travel with the weights
+                wd["s1"], wd["s2"] = w[p + "feed_forward.experts.w_1.scale"], w[p + "feed_forward.experts.w_2.scale"]
+            self.layers.append({"w": wd,
                                 "ln": (w[p + "norm_final.weight"], w[p + "norm_final.bias"], 1e-12)})
 
     def forward(self, feat, feat_len):

@@ -64,10 +64,26 @@ def moe_expert_workspace_size(S, E, D, F):
     return _lib.load().m3_moe_expert_workspace_size(S, E, D, F)
 
 
-def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None):
+def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None,
+                   w1_scale=None, w2_scale=None):
     """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue.
     w1 / w2 fp32, or both bf16 (bf16 MFMA, fp32 accumulate; biases stay fp32)."""
     lib = _lib.load()
+    if w1.dtype == torch.float8_e4m3fn:        # W8A16: e4m3 weights + per-row scales
+        assert w2.dtype == torch.float8_e4m3fn and w1_scale is not None and w2_scale is not None
+        S, D = x.shape
+        E, F = w1.shape[0], w1.shape[1]
+        need = moe_expert_workspace_size(S, E, D, F)
+        if workspace is None:
+            workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        g, b, eps = ln if ln is not None else (None, None, 0.0)
+        check(lib.m3_moe_expert_ffn_fp8(_f32(x), _i32(gate_idx.reshape(-1)), _p(w1), _f32(w1_scale), _f32(b1), _p(w2),
+                                        _f32(w2_scale), _f32(b2), S, E, D, F,
+                                        _f32(gate_value.reshape(-1) if gate_value is not None else None), _f32(resid),
+                                        float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
+                                        workspace.numel(), _stream()), "m3_moe_expert_ffn_fp8")
+        return y
     if w1.dtype == torch.bfloat16:
         assert w2.dtype == torch.bfloat16 and w1.is_contiguous() and w2.is_contiguous()
         S, D = x.shape

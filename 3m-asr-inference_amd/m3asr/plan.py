@@ -210,17 +210,36 @@ def is_gemm_weight(name):
     return _GEMM_WEIGHT.search(name) is not None
 
 
+FP8_MAX = 448.0    # largest finite OCP e4m3 value
+
+
+def quantize_fp8_rows(w, dims):
+    """Per-output-row symmetric quantisation to OCP e4m3 (torch.float8_e4m3fn = the format of gfx950's fp8 conversions):
+    scale = amax over `dims` / 448, q = round_to_nearest_even(w / scale).  Returns (q fp8, scale fp32 with `dims` removed)."""
+    amax = w.abs().amax(dim=dims, keepdim=True).clamp_min(1e-30)
+    scale = (amax / FP8_MAX).float()
+    q = (w / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).contiguous()
+    return q, scale.squeeze(dims).contiguous()
+
+
 def cast_gemm_weights(packed, cfg: EncoderConfig):
     """Store the GEMM weights in cfg.weight_dtype ("f32" = no-op, "bf16" = round to nearest even).  The reference
     wires --fp16 / plugin_data_type = 1 (builder.py:160, builder_helper.py:47-57,109-123) without finishing it; bf16 is
-    the 16-bit type on CDNA4.  The folded LayerNorm's column sums are recomputed from the ROUNDED weights, so that
+    the 16-bit type on CDNA4.  "fp8": additionally the expert weights (94 % of the parameters) become e4m3 with one scale per
+    output row (W8A16: dequantised to bf16 at the MFMA input).  The folded LayerNorm's column sums are recomputed from the ROUNDED weights, so that
     y = rstd * (a . W'^T - mean * wsum) stays an exact identity for the weights the kernel really multiplies by."""
     if cfg.weight_dtype == "f32":
         return packed
-    assert cfg.weight_dtype == "bf16", cfg.weight_dtype
+    assert cfg.weight_dtype in ("bf16", "fp8"), cfg.weight_dtype
     out = OrderedDict()
     for k, v in packed.items():
-        if is_gemm_weight(k) and v.dtype == torch.float32:
+        if cfg.weight_dtype == "fp8" and v.dtype == torch.float32 and k.endswith("experts.w_1.weight"):
+            q, sc = quantize_fp8_rows(v, dims=(2,))                       # [E][F][D]: one scale per (e, f)
+            out[k], out[k[:-len("weight")] + "scale"] = q, sc
+        elif cfg.weight_dtype == "fp8" and v.dtype == torch.float32 and k.endswith("experts.w_2.weight_sliced"):
+            q, sc = quantize_fp8_rows(v, dims=(1, 3))                     # [E][F/64][D][64]: one scale per (e, d)
+            out[k], out[k[:-len("weight_sliced")] + "scale"] = q, sc
+        elif is_gemm_weight(k) and v.dtype == torch.float32:
             out[k] = v.to(torch.bfloat16).contiguous()
         else:
             out[k] = v
@@ -230,8 +249,9 @@ def cast_gemm_weights(packed, cfg: EncoderConfig):
     return out
 
 
-_DTYPES = {"f32": (torch.float32, "<f4", 4), "bf16": (torch.bfloat16, "<u2", 2), "i32": (torch.int32, "<i4", 4)}
-_DTYPE_NAME = {torch.float32: "f32", torch.bfloat16: "bf16", torch.int32: "i32"}
+_DTYPES = {"f32": (torch.float32, "<f4", 4), "bf16": (torch.bfloat16, "<u2", 2), "i32": (torch.int32, "<i4", 4),
+           "fp8": (torch.float8_e4m3fn, "u1", 1)}
+_DTYPE_NAME = {torch.float32: "f32", torch.bfloat16: "bf16", torch.int32: "i32", torch.float8_e4m3fn: "fp8"}
 
 
 def save_plan(path, cfg: EncoderConfig, packed, extra=None):
@@ -250,6 +270,8 @@ def save_plan(path, cfg: EncoderConfig, packed, extra=None):
         for k, v in packed.items():
             if v.dtype == torch.bfloat16:
                 b = v.contiguous().view(torch.int16).numpy().astype("<i2", copy=False).tobytes()
+            elif v.dtype == torch.float8_e4m3fn:
+                b = v.contiguous().view(torch.uint8).numpy().tobytes()
             else:
                 b = v.contiguous().numpy().astype(_DTYPES[_DTYPE_NAME[v.dtype]][1], copy=False).tobytes()
             f.write(b)
@@ -274,6 +296,9 @@ def load_plan(path):
         if tdt == torch.bfloat16:
             arr = np.frombuffer(mm, dtype="<i2", count=n, offset=base + off).reshape(shape)
             packed[k] = torch.from_numpy(np.array(arr, copy=True)).view(torch.bfloat16)
+        elif tdt == torch.float8_e4m3fn:
+            arr = np.frombuffer(mm, dtype="u1", count=n, offset=base + off).reshape(shape)
+            packed[k] = torch.from_numpy(np.array(arr, copy=True)).view(torch.float8_e4m3fn)
         else:
             arr = np.frombuffer(mm, dtype=ndt, count=n, offset=base + off).reshape(shape)
             packed[k] = torch.from_numpy(np.array(arr, copy=True))

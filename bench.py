@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--fuse-route", action="store_true",
                     help="router + SoftmaxTopK + ScatterMapping as one single-workgroup launch per layer (275 instead of "
                          "292 kernels; measured 2-3 %% slower than the staged path, so off by default)")
-    ap.add_argument("--weight-dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--weight-dtype", choices=["f32", "bf16", "fp8"], default="f32",
                     help="storage of the GEMM weights (bf16 = BASELINE.json configs[2]; the headline metric is f32)")
     ap.add_argument("--varlen", default="", help="LO-HI: utterance lengths drawn from U[LO,HI] frames (configs[2]: 50-500)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
@@ -219,8 +219,9 @@ def main():
         for li in range(cfg.num_blocks):
             g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
             touched.append(len(np.unique(g[g >= 0])))
-        wsz = 2 if cfg.weight_dtype == "bf16" else 4        # expert weights in weight_dtype, biases and rows fp32
-        bytes_alg = np.array([t_ * (2 * D * F * wsz + (F + D) * 4) + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
+        wsz = {"f32": 4, "bf16": 2, "fp8": 1}[cfg.weight_dtype]   # expert weights in weight_dtype, biases / scales / rows fp32
+        extra = (F + D) * 4 * (2 if cfg.weight_dtype == "fp8" else 1)   # biases (+ per-row scales)
+        bytes_alg = np.array([t_ * (2 * D * F * wsz + extra) + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
         # duration of the roofline kernel IN SITU: whole forwards are enqueued stage by stage on the engine stream
         # (the GPU stays the bottleneck: ~3.5 us host cost per launch vs ~8 us per kernel) with HIP events only around
         # each layer's expert launch, so the kernel sees the cache state of a real forward -- repeated in isolation its
@@ -248,7 +249,7 @@ def main():
         # full bench.py segfaults inside the profiler's counter collection on this pool), scaled by the touched-expert
         # count of this run (the probe's routing touched 25.33 experts per layer)
         traffic = None
-        kname = "expert_ffn_bf16w_kernel" if cfg.weight_dtype == "bf16" else "expert_ffn_f32_kernel"
+        kname = {"f32": "expert_ffn_f32_kernel", "bf16": "expert_ffn_bf16w_kernel", "fp8": "expert_ffn_w8_kernel"}[cfg.weight_dtype]
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_expert.json")
         if os.path.exists(pmc) and B == 1 and T == 206:
             try:
@@ -312,10 +313,12 @@ def main():
                "dtype": cfg.weight_dtype, "data": "synthetic",
                "config": {"workload": "%d-layer %d-expert %s, batch=%dx%d frames per GPU%s, all experts local "
                                       "(BASELINE.json configs[%d])" % (
-                                          cfg.num_blocks, cfg.num_experts, "fp32" if cfg.weight_dtype == "f32" else
-                                          "bf16 weights / bf16 MFMA / fp32 accumulate + activations", B, T,
+                                          cfg.num_blocks, cfg.num_experts,
+                                          {"f32": "fp32", "bf16": "bf16 weights / bf16 MFMA / fp32 accumulate + activations",
+                                           "fp8": "fp8 (e4m3) expert weights + bf16 dense weights / bf16 MFMA / fp32 accumulate "
+                                                  "+ activations"}[cfg.weight_dtype], B, T,
                                           (" (lengths U[%s], %d real frames)" % (args.varlen, n_frames)) if args.varlen else "",
-                                          1 if cfg.weight_dtype == "f32" else 2),
+                                          {"f32": 1, "bf16": 2, "fp8": 4}[cfg.weight_dtype]),
                           "layers": cfg.num_blocks, "experts": cfg.num_experts, "frames": T, "batch_per_gpu": B,
                           "parallelism": "replicas x%d" % world, "streams_per_gpu": len(ctxs),
                           "latency_ms_one_stream": round(latency_ms, 4), "hip_graph": use_graph,

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* m3_stream; /* hipStream_t */
 
-enum m3_dtype { M3_F32 = 0, M3_F16 = 1, M3_I8 = 2, M3_I32 = 3, M3_BF16 = 4 };
+enum m3_dtype { M3_F32 = 0, M3_F16 = 1, M3_I8 = 2, M3_I32 = 3, M3_BF16 = 4, M3_FP8 = 5 /* OCP e4m3 */ };
 
 /* activation / element-wise codes shared by several entry points */
 enum m3_act { M3_ACT_NONE = 0, M3_ACT_RELU = 1, M3_ACT_SILU = 2, M3_ACT_GLU = 3, M3_ACT_SIGMOID = 4, M3_ACT_LOG = 5 };
@@ -123,6 +123,14 @@ int m3_moe_expert_ffn_bf16(const float* x, const int32_t* gate_idx, const void* 
                            const float* gate_value, const float* resid, float alpha, const float* ln_gamma,
                            const float* ln_beta, float ln_eps, float* y, void* workspace, size_t workspace_bytes,
                            m3_stream stream);
+/* fp8 expert weights (W8A16): w1 / w2 hold OCP e4m3 bytes, W[e][n][k] ~ scale[e][n] * q[e][n][k] with w1_scale [E][F],
+ * w2_scale [E][D]; the weights are dequantised to bf16 at the MFMA input (exact), rows and H are rounded to bf16 as in
+ * the bf16 form, accumulation fp32.  1.05 MB per touched expert at D=512, F=1024. */
+int m3_moe_expert_ffn_fp8(const float* x, const int32_t* gate_idx, const void* w1, const float* w1_scale,
+                          const float* b1, const void* w2, const float* w2_scale, const float* b2, int S, int num_expert,
+                          int idim, int hidden_units, const float* gate_value, const float* resid, float alpha,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* workspace,
+                          size_t workspace_bytes, m3_stream stream);
 /* The tail of the MoE layer on rows that are already in scattered (expert-sorted) order, e.g. rows that came back
  * from the expert-parallel all-to-all:  out[s] = LayerNorm( resid[s] + alpha * gate_value[s] * rows[mapping[s]] )
  * (rows with mapping < 0 contribute 0; gate_value / resid / ln_* may be NULL).  = local_gather
@@ -248,7 +256,9 @@ typedef struct m3_engine_config {
                                   * captured hipGraph (LRU): 0 = default 7, -1 = none.  A parked binding's workspace must be
                                   * left untouched by the caller (it holds the folded positional projection). */
   int32_t weight_dtype;          /* M3_F32 / M3_BF16: storage of the GEMM weights (linear / point-wise conv /
-                                  * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32 */
+                                  * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32.
+                                  * M3_FP8: expert w_1 / w_2 in e4m3 with per-row scales ("...w_1.scale", "...w_2.scale"),
+                                  * the other GEMM weights bf16 */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {
