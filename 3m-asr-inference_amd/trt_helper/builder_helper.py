@@ -73,6 +73,8 @@ class BuilderHelper:
         if config.use_int8 or int(config.plugin_data_type) not in (0, 1):
             raise RuntimeError("int8 / fp8 calibration is not implemented (fp32 and the 16-bit --fp16 mode are)")
         self.weight_dtype = "bf16" if (config.use_fp16 or int(config.plugin_data_type) == 1) else "f32"
+        if getattr(config, "use_fp8", False):
+            self.weight_dtype = "fp8"
         self.device = torch.device(device)
         self.profiles = {}
         self.model, self.model_cfg = None, None

@@ -42,6 +42,8 @@ def build_trt(model, args, input_dim, plan_name, prior=None, profile=None):
     cfg.max_workspace_size = 8
     if args.fp16:
         cfg.use_fp16, cfg.plugin_data_type = True, trt.DataType.HALF
+    if args.fp8:
+        cfg.use_fp8 = True                          # e4m3 expert weights + bf16 dense weights (W8A16), no calibration needed
     if args.int8:
         cfg.use_int8 = True
     builder_helper = trt_helper.BuilderHelper(cfg, logger, None)
@@ -109,6 +111,7 @@ if __name__ == "__main__":
                    help="output log_softmax(logits) (- log prior) instead of raw logits (reference builder.py:77-81)")
     p.add_argument("-f", "--fp16", action="store_true")
     p.add_argument("-i", "--int8", action="store_true")
+    p.add_argument("--fp8", action="store_true", help="expert weights as fp8 e4m3 with per-row scales, dense weights bf16")
     p.add_argument("-t", "--strict", action="store_true")
     p.add_argument("-w", "--workspace-size", default=1000, type=int)
     p.add_argument("-tcf", "--timing-cache-file", required=False)

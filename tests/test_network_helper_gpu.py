@@ -103,3 +103,21 @@ def test_builder_fp16_flag_writes_a_bf16_plan(tmp_path):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "infer.py"), "-p", p16, "-i", os.path.join(d, "feat.npy")],
                                   env=env, text=True)
     assert "time=" in out and "outputs.shape:(1, 50, 16)" in out
+
+
+def test_builder_fp8_flag_writes_an_fp8_plan(tmp_path):
+    """--fp8: e4m3 expert weights + per-row scales, bf16 dense weights (needs dims that are multiples of 64)."""
+    d = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "3m-asr-inference_amd"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_checkpoint.py"), "--out-dir", d,
+                           "--layers", "1", "--seed", "3"], env=env)
+    plan = os.path.join(d, "enc8.plan")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "builder.py"), "-c", os.path.join(d, "config.yaml"),
+                                   "-m", os.path.join(d, "model.pt"), "-o", plan, "--opt-shape", "2x64", "--fp8"],
+                                  env=env, text=True)
+    assert "fused engine vs op-by-op emission" in out
+    from m3asr.plan import load_plan
+    cfg8, packed8, _ = load_plan(plan)
+    assert cfg8.weight_dtype == "fp8"
+    assert packed8["blocks.0.feed_forward.experts.w_1.weight"].dtype == torch.float8_e4m3fn
+    assert packed8["blocks.0.feed_forward.experts.w_1.scale"].dtype == torch.float32
