@@ -152,6 +152,18 @@ def test_shape_cache_replays_graphs_across_alternating_shapes():
     assert torch.equal(out2, ref(f2.cuda(), lens[(1, 206)].view(1, -1).cuda()))
 
 
+def test_engine_longest_profile_length():
+    """The reference profiles its engine up to 6100 frames (builder.py:58-64): long-batch kernels (LDS-tiled GEMMs, grouped
+    tiled expert FFN, row-parallel top-1) and 32-bit index arithmetic at S = 3 x 1524 rows, ragged lengths."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=1)
+    feat = torch.rand(3, 6100, cfg.input_dim, generator=torch.Generator().manual_seed(0))
+    fl = torch.tensor([6100, 3001, 777], dtype=torch.int32)
+    want = encoder_forward(w, cfg, feat, fl)
+    eng, out = _run(cfg, w, feat, fl)
+    _check(out, want, sub_len(fl.long()))
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()
