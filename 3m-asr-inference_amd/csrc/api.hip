@@ -190,6 +190,11 @@ int m3_subsample_conv1_cmvn(const float* feat, const float* w9c, const float* bi
   M3_REQUIRE((cmvn_mean == nullptr) == (cmvn_istd == nullptr), "subsample_conv1: cmvn mean and istd go together");
   return launch_conv1_relu(feat, w9c, bias, cmvn_mean, cmvn_istd, B, T, idim, C, out, (hipStream_t)stream);
 }
+int m3_conv2d_3x3s2_first(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C, int act,
+                          float* out, m3_stream stream) {
+  M3_REQUIRE(act == M3_ACT_NONE || act == M3_ACT_RELU, "conv2d: act %d (none / relu)", act);
+  return launch_conv1_relu(feat, w9c, bias, nullptr, nullptr, B, T, idim, C, out, (hipStream_t)stream, act == M3_ACT_RELU);
+}
 int m3_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D, float* y,
             m3_stream stream) {
   M3_REQUIRE(x && mean && istd && y, "cmvn: null pointer");
@@ -199,16 +204,23 @@ int m3_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows
   M3_REQUIRE(x && y && n > 0, "log_softmax_bias: bad arguments");
   return launch_log_softmax_bias(x, bias, y, rows, n, (hipStream_t)stream);
 }
+int m3_conv2d_3x3s2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, int act, float* out,
+                    m3_stream stream);
 int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, float* out,
                        m3_stream stream) {
+  return m3_conv2d_3x3s2(in, w, bias, B, T1, F1, C, M3_ACT_RELU, out, stream);
+}
+int m3_conv2d_3x3s2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, int act, float* out,
+                    m3_stream stream) {
   M3_REQUIRE(T1 >= 3 && F1 >= 3, "subsample_conv2: input (%d,%d) smaller than the kernel", T1, F1);
+  M3_REQUIRE(act == M3_ACT_NONE || act == M3_ACT_RELU || act == M3_ACT_SILU, "conv2d: act %d", act);
   GemmParams p;
   p.mode = GEMM_A_CONV3X3S2;
   p.A = in; p.lda = 4;
   p.conv_T1 = T1; p.conv_F1 = F1; p.conv_T2 = (T1 - 3) / 2 + 1; p.conv_F2 = (F1 - 3) / 2 + 1; p.conv_C = C;
   p.W = w; p.bias = bias; p.Y = out; p.ldy = C;
   p.M = B * p.conv_T2 * p.conv_F2; p.N = C; p.K = 9 * C;
-  p.act = ACT_RELU;
+  p.act = act;
   return launch_gemm_f32(p, (hipStream_t)stream);
 }
 

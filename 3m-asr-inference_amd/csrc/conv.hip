@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ cmvn_mean,
                                                          const float* __restrict__ cmvn_istd, int T, int idim, int T1,
-                                                         int F1, int C, float* __restrict__ out, size_t n4) {
+                                                         int F1, int C, float* __restrict__ out, size_t n4, int relu) {
   const int c4n = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4n) * 4;
@@ -131,19 +131,19 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
       }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    for (int j = 0; j < 4; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
     stg4(out + i * 4, acc);
   }
 }
 
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
-                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream) {
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu) {
   M3_REQUIRE(T >= 3 && idim >= 3, "subsampling: input (T=%d, idim=%d) shorter than the 3x3 kernel", T, idim);
   M3_REQUIRE((C & 3) == 0, "subsampling: channels=%d must be a multiple of 4", C);
   const int T1 = (T - 3) / 2 + 1, F1 = (idim - 3) / 2 + 1;
   const size_t n4 = (size_t)B * T1 * F1 * (C / 4);
   hipLaunchKernelGGL(conv1_relu_kernel, dim3(grid1d(n4, 4096)), dim3(256), 0, stream,
-                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4);
+                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4, relu);
   M3_LAUNCH_CHECK();
   return 0;
 }

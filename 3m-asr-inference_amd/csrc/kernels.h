@@ -136,7 +136,7 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream);
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
-                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream);
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu = 1);
 int launch_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D,
                 float* y, hipStream_t stream);
 int launch_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, hipStream_t stream);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "m3_linear": (_i, [_P(LinearDesc), _vp]),
     "m3_linear_workspace_size": (_sz, [_P(LinearDesc)]),
     "m3_linear_ws": (_i, [_P(LinearDesc), _vp, _sz, _vp]),
+    "m3_conv2d_3x3s2_first": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "m3_conv2d_3x3s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m3_layer_norm": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_relpos_attention": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "m3_dwconv_ln_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),

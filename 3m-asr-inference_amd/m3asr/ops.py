@@ -208,14 +208,15 @@ def dwconv_ln_silu(z, w_kc, bias, gamma, beta, eps, B, T):
     return out
 
 
-def subsample_conv1(feat, w9c, bias):
+def subsample_conv1(feat, w9c, bias, act=_lib.ACT_RELU):
+    """Conv2d(1, C, 3, stride 2) on (B,T,idim) -> channel-last (B,T1,F1,C); act = ACT_RELU (fused, default) or ACT_NONE."""
     lib = _lib.load()
     B, T, idim = feat.shape
     Cc = w9c.shape[1]
     T1, F1 = (T - 3) // 2 + 1, (idim - 3) // 2 + 1
     out = torch.empty(B, T1, F1, Cc, dtype=torch.float32, device=feat.device)
-    check(lib.m3_subsample_conv1(_f32(feat), _f32(w9c), _f32(bias), B, T, idim, Cc, _p(out), _stream()),
-          "m3_subsample_conv1")
+    check(lib.m3_conv2d_3x3s2_first(_f32(feat), _f32(w9c), _f32(bias), B, T, idim, Cc, int(act), _p(out), _stream()),
+          "m3_conv2d_3x3s2_first")
     return out
 
 
@@ -235,13 +236,14 @@ def log_softmax_bias(x, bias=None):
     return y
 
 
-def subsample_conv2(x, w, bias):
+def subsample_conv2(x, w, bias, act=_lib.ACT_RELU):
+    """Conv2d(C, C, 3, stride 2) on channel-last (B,T1,F1,C) as implicit GEMM; act = ACT_RELU (fused, default) or ACT_NONE."""
     lib = _lib.load()
     B, T1, F1, Cc = x.shape
     T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
     out = torch.empty(B, T2, F2, Cc, dtype=torch.float32, device=x.device)
-    check(lib.m3_subsample_conv2(_f32(x), _f32(w), _f32(bias), B, T1, F1, Cc, _p(out), _stream()),
-          "m3_subsample_conv2")
+    check(lib.m3_conv2d_3x3s2(_f32(x), _f32(w), _f32(bias), B, T1, F1, Cc, int(act), _p(out), _stream()),
+          "m3_conv2d_3x3s2")
     return out
 
 
@@ -348,6 +350,10 @@ def softmax_lastdim(x):
 def batched_matmul(a, b, transpose_b=False):
     """a (..., M, K) @ b (..., K, N) (or b (..., N, K) transposed); leading dims equal or 1 in b/a."""
     lib = _lib.load()
+    if b.dim() < a.dim():          # fewer leading dims: broadcast like torch.matmul
+        b = b.reshape((1,) * (a.dim() - b.dim()) + tuple(b.shape))
+    elif a.dim() < b.dim():
+        a = a.reshape((1,) * (b.dim() - a.dim()) + tuple(a.shape))
     M, K = a.shape[-2:]
     N = b.shape[-2] if transpose_b else b.shape[-1]
     lead = [max(x, y) for x, y in zip(a.shape[:-2], b.shape[:-2])]

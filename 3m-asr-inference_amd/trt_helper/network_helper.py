@@ -277,7 +277,9 @@ class NetworkHelper:
         return ops.layer_norm(x, self._dev(layer.weight), self._dev(layer.bias), layer.eps)
 
     def addConv2d(self, layer, x, layer_name=None, precision=None):
-        """NCHW in/out.  Implemented for what Conv2dSubsampling4 emits: 3x3, stride 2, no padding, groups 1."""
+        """NCHW in/out, the convolution alone (the ReLU that follows it in Conv2dSubsampling4 is a separate addReLU in the
+        emission, as in the reference; the fused engine uses the conv + ReLU kernels).  Implemented for what
+        Conv2dSubsampling4 emits: 3x3, stride 2, no padding, groups 1."""
         if tuple(layer.kernel_size) != (3, 3) or tuple(layer.stride) != (2, 2) or tuple(layer.padding) != (0, 0) \
                 or layer.groups != 1 or tuple(layer.dilation) != (1, 1):
             raise RuntimeError("nn.Conv2d other than 3x3/stride 2/no padding not support!")
@@ -288,13 +290,13 @@ class NetworkHelper:
             wp = self._const_cache.get(key)
             if wp is None:
                 wp = self._const_cache[key] = w.reshape(O, 9).t().contiguous().to(self.device)
-            y = ops.subsample_conv1(x.reshape(x.shape[0], x.shape[2], x.shape[3]).contiguous(), wp, b)
+            y = ops.subsample_conv1(x.reshape(x.shape[0], x.shape[2], x.shape[3]).contiguous(), wp, b, act=_lib.ACT_NONE)
         else:
             key = ("c2", w.data_ptr())
             wp = self._const_cache.get(key)
             if wp is None:
                 wp = self._const_cache[key] = w.permute(0, 2, 3, 1).contiguous().to(self.device)
-            y = ops.subsample_conv2(ops.permute_copy(x, (0, 2, 3, 1)), wp, b)
+            y = ops.subsample_conv2(ops.permute_copy(x, (0, 2, 3, 1)), wp, b, act=_lib.ACT_NONE)
         return ops.permute_copy(y, (0, 3, 1, 2))
 
     def addConv1d(self, layer, x, layer_name=None, precision=None):

@@ -195,6 +195,12 @@ int m3_subsample_conv1(const float* feat, const float* w9c, const float* bias, i
 /* the same with global CMVN folded into the input read (mean / istd [idim], may be NULL) */
 int m3_subsample_conv1_cmvn(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
                             const float* cmvn_istd, int B, int T, int idim, int C, float* out, m3_stream stream);
+/* The plain operators behind network_helper.addConv2d (torch_network_helper.py:227-251; nn.Conv2d 3x3 / stride 2 / no
+ * padding, channel-last data): act = M3_ACT_NONE gives the convolution alone, M3_ACT_RELU the fused form above. */
+int m3_conv2d_3x3s2_first(const float* feat, const float* w9c, const float* bias, int B, int T, int idim, int C, int act,
+                          float* out, m3_stream stream);
+int m3_conv2d_3x3s2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C, int act, float* out,
+                    m3_stream stream);
 /* second conv (C->C, 3x3, s2) + ReLU as implicit GEMM: in (B,T1,F1,C) -> out (B,T2,F2,C); w [C][3][3][C]. */
 int m3_subsample_conv2(const float* in, const float* w, const float* bias, int B, int T1, int F1, int C,
                        float* out, m3_stream stream);
