@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
                                                               const float* __restrict__ pos_u,
                                                               const float* __restrict__ pos_v,
                                                               const int32_t* __restrict__ row_len, int T, int D,
-                                                              float scale, float* __restrict__ out, int ldo) {
+                                                              float scale, float* __restrict__ out, int ldo, int out_bf16) {
   constexpr int KS = DK / 16;
   __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
   __shared__ float mo[4][16][DK + 1];   // per-wave partial O
@@ -131,20 +131,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
       l_tot += ml[w][i] * f;
       acc += mo[w][i][d] * f;
     }
-    out[(brow + qrow) * ldo + h * DK + d] = acc / l_tot;
+    if (out_bf16) reinterpret_cast<bf16_t*>(out)[(brow + qrow) * ldo + h * DK + d] = (bf16_t)(acc / l_tot);
+    else out[(brow + qrow) * ldo + h * DK + d] = acc / l_tot;
   }
 }
 
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream) {
+                            float* out, int ldo, hipStream_t stream, int out_bf16) {
   M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
   M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0, "attention: row strides must be multiples of 4");
   dim3 grid(cdiv(T, 16), H, B);
   const int D = H * dk;
 #define M3_ATT_CASE(DK_)                                                                                   \
   hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
-                     pos_v, row_len, T, D, scale, out, ldo)
+                     pos_v, row_len, T, D, scale, out, ldo, out_bf16)
   switch (dk) {
     case 16: M3_ATT_CASE(16); break;
     case 32: M3_ATT_CASE(32); break;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int T,
-                                                              int D, int K, float* __restrict__ out) {
+                                                              int D, int K, float* __restrict__ out, int out_bf16) {
   __shared__ float red[2][16];
   const int row = blockIdx.x;
   const int b = row / T, t = row % T;
@@ -81,12 +81,19 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
   if (live) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
-    stg4(out + (size_t)row * D + c, v);
+    if (out_bf16) {
+      bf16x4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D + c) = h;
+    } else {
+      stg4(out + (size_t)row * D + c, v);
+    }
   }
 }
 
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
-                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream) {
+                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16) {
   M3_REQUIRE((D & 3) == 0 && D <= 4096, "dwconv: channels=%d must be a multiple of 4 (<=4096)", D);
   M3_REQUIRE((K & 1) == 1, "dwconv: kernel size %d must be odd (non-causal)", K);
   const int rows = B * T;
@@ -94,10 +101,10 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
   const int threads = (int)align_up(D / 4, 64);
   if (K <= 15)
     hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out);
+                       eps, T, D, K, out, out_bf16);
   else
     hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out);
+                       eps, T, D, K, out, out_bf16);
   M3_LAUNCH_CHECK();
   return 0;
 }
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ cmvn_mean,
                                                          const float* __restrict__ cmvn_istd, int T, int idim, int T1,
-                                                         int F1, int C, float* __restrict__ out, size_t n4, int relu) {
+                                                         int F1, int C, float* __restrict__ out, size_t n4, int relu, int out_bf16) {
   const int c4n = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % c4n) * 4;
@@ -132,18 +139,25 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
-    stg4(out + i * 4, acc);
+    if (out_bf16) {
+      bf16x4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (bf16_t)acc[j];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + i * 4) = h;
+    } else {
+      stg4(out + i * 4, acc);
+    }
   }
 }
 
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
-                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu) {
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu, int out_bf16) {
   M3_REQUIRE(T >= 3 && idim >= 3, "subsampling: input (T=%d, idim=%d) shorter than the 3x3 kernel", T, idim);
   M3_REQUIRE((C & 3) == 0, "subsampling: channels=%d must be a multiple of 4", C);
   const int T1 = (T - 3) / 2 + 1, F1 = (idim - 3) / 2 + 1;
   const size_t n4 = (size_t)B * T1 * F1 * (C / 4);
   hipLaunchKernelGGL(conv1_relu_kernel, dim3(grid1d(n4, 4096)), dim3(256), 0, stream,
-                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4, relu);
+                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4, relu, out_bf16);
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -80,6 +80,7 @@ struct m3_engine {
     const float* feat = nullptr; const int32_t* feat_len = nullptr; float* logits = nullptr;
     void* ws = nullptr; size_t ws_bytes = 0;
     float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
+    bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     std::vector<Stage> stages;
     std::unordered_map<std::string, Buf> buffers;
     int n_kernels = 0;
@@ -219,6 +220,7 @@ struct Carver {
 struct Plan {
   int32_t* lens;
   float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
+  void* xb;                             // bf16 copy of the residual stream (16-bit modes, long batches)
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
   void* moe_ws; size_t moe_ws_bytes;
   float* splitk; size_t splitk_bytes;   // split-K partials of conv2 / subsampling Linear (fp32 plans, short inputs)
@@ -241,6 +243,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.c2 = cv.take<float>((size_t)S * F2 * D);
   p.x = cv.take<float>((size_t)S * D);
   p.emb = cv.take<float>((size_t)S * D);
+  p.xb = cv.take<uint16_t>((size_t)S * D);
   p.h1 = cv.take<float>((size_t)S * F);
   p.qkv = cv.take<float>((size_t)S * 3 * D);
   p.pbuf = cv.take<float>((size_t)Tp * D * (c.num_blocks + c.embed_blocks));
@@ -301,8 +304,10 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   float* c1 = pl.c1; float* c2 = pl.c2;
   const int idim = c.input_dim;
   const float* cm = e->cmvn_mean; const float* ci = e->cmvn_istd;
-  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s); });
+  const bool a16 = e->cur.a16;    // c1, c2 only feed GEMMs: kept as bf16; the Linear also writes the bf16 copy of x
+  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s, 1, a16); });
   GemmParams g;
+  g.a_bf16 = a16; g.y_bf16 = a16;
   g.mode = GEMM_A_CONV3X3S2; g.A = c1; g.lda = 4;
   g.conv_T1 = T1; g.conv_F1 = F1; g.conv_T2 = T2; g.conv_F2 = F2; g.conv_C = D;
   g.W = w.c2w; g.bias = w.c2b; g.Y = c2; g.ldy = D; g.M = B * T2 * F2; g.N = D; g.K = 9 * D; g.act = ACT_RELU;
@@ -312,6 +317,8 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   GemmParams l;
   l.A = c2; l.lda = F2 * D; l.W = w.out.w; l.bias = w.out.b; l.Y = xout; l.ldy = D;
   l.M = B * T2; l.N = D; l.K = F2 * D; l.alpha = sqrtf((float)D);
+  l.a_bf16 = a16;
+  if (a16) { l.Yb = pl.xb; l.ldyb = D; }
   add_gemm(e, pfx + "linear", l);
 }
 
@@ -323,20 +330,29 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   const int32_t* lens = pl.lens;
   const float eps = 1e-12f;  // all block LayerNorms (fmoe_transformer.py:54-65)
 
+  // 16-bit modes, long batches: GEMM A operands come as bf16 -- the copy xb of the residual stream (written by every
+  // kernel that writes x) and bf16 h1 / ctx / dw -- because these GEMMs are bound by the traffic of their fp32 A operand
+  const bool a16 = e->cur.a16;
+  void* xb = pl.xb;
+  auto from_xb = [&](GemmParams& g) { if (a16) { g.A = (const float*)xb; g.a_bf16 = 1; } };
+  auto also_xb = [&](GemmParams& g) { if (a16) { g.Yb = xb; g.ldyb = D; } };
   {  // x += 0.5 * FFN_macaron(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.mac1.w; g.bias = w.mac1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
     g.ln_wsum = w.mac1.wsum; g.ln_eps = eps; g.act = ACT_SILU;   // norm_ff_macaron is folded into w_1 (plan.py)
+    from_xb(g); g.y_bf16 = a16;
     add_gemm(e, pfx + "ffn_macaron.w1", g);
     GemmParams h;
     h.A = pl.h1; h.lda = F; h.W = w.mac2.w; h.bias = w.mac2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
     h.alpha = 0.5f; h.resid = x; h.ldr = D;
+    h.a_bf16 = a16; also_xb(h);
     add_gemm(e, pfx + "ffn_macaron.w2", h);
   }
   {  // x += MHA(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.qkv.w; g.bias = w.qkv.b; g.Y = pl.qkv; g.ldy = 3 * D; g.M = S; g.N = 3 * D; g.K = D;
     g.ln_wsum = w.qkv.wsum; g.ln_eps = eps;                  // norm_mha is folded into the qkv weight
+    from_xb(g);
     add_gemm(e, pfx + "att.qkv", g);
     // p = linear_pos(pos_emb) of all blocks comes from ONE GEMM per forward ("pos_all" stage):
     // block i's slice is columns [i*D, (i+1)*D) of pbuf [T'][n_blocks*D]
@@ -347,11 +363,12 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
-      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s);
+      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16);
     });
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
     o.resid = x; o.ldr = D;
+    o.a_bf16 = a16; also_xb(o);
     add_gemm(e, pfx + "att.out", o);
   }
   {  // x += ConvModule(LN(x))
@@ -359,29 +376,34 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     g.A = x; g.lda = D; g.W = w.pw1.w; g.bias = w.pw1.b; g.Y = pl.glu; g.ldy = D; g.M = S; g.N = 2 * D; g.K = D;
     g.ln_wsum = w.pw1.wsum; g.ln_wbeta = w.pw1.wbeta; g.ln_eps = eps; g.act = ACT_GLU;   // norm_conv folded into pw1
     g.row_len = lens; g.rows_per_batch = Tp; g.mask_in = 1;
+    from_xb(g);
     add_gemm(e, pfx + "conv.pw1_glu", g);
     const float* glu = pl.glu; float* dw = pl.dw;
     const float* dww = w.dw_w; const float* dwb = w.dw_b;
     const float* ng = cnn_ln ? w.n_cnn.g : nullptr; const float* nb = cnn_ln ? w.n_cnn.b : nullptr;
     add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
-      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s);
+      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16);
     });
     GemmParams h;
     h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
     h.row_len = lens; h.rows_per_batch = Tp; h.mask_out = 1; h.resid = x; h.ldr = D;
+    h.a_bf16 = a16; also_xb(h);
     add_gemm(e, pfx + "conv.pw2", h);
   }
   if (!moe) {  // x = LN_final(x + 0.5 * FFN(LN(x)))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.ff1.w; g.bias = w.ff1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
     g.ln_wsum = w.ff1.wsum; g.ln_eps = eps; g.act = ACT_SILU;   // norm_ff is folded into w_1
+    from_xb(g); g.y_bf16 = a16;
     add_gemm(e, pfx + "ffn.w1", g);
     GemmParams h;
     h.A = pl.h1; h.lda = F; h.W = w.ff2.w; h.bias = w.ff2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = F;
     h.alpha = 0.5f; h.resid = x; h.ldr = D;
+    h.a_bf16 = a16;                                   // (x is rewritten by norm_final below: no bf16 copy here)
     add_gemm(e, pfx + "ffn.w2", h);
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
-    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s); });
+    void* xbo = a16 ? xb : nullptr;
+    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo); });
   } else {  // x = LN_final(x + 0.5 * gate * Expert_g(LN(x)))     (positionwise_feed_forward.py:209-265)
     const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
     const int Etot = c.num_experts * world, E = c.num_experts, De = c.embed_dim;
@@ -462,7 +484,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
-      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s);
+      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
     });
     const std::string b = pfx.substr(0, pfx.size() - 1);
     e->cur.buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
@@ -623,6 +645,14 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.feat = feat; e->cur.feat_len = feat_len; e->cur.logits = logits; e->cur.ws = workspace; e->cur.ws_bytes = workspace_bytes;
   e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false;
   e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
+  {
+    // bf16 activation operands need every GEMM that reads or rewrites them on the LDS-tiled kernel: the narrowest ones
+    // are the D x D projections; the expert-parallel driver replaces the combine stage with its own op (no bf16 copy)
+    GemmParams t;
+    t.M = B * Tp; t.N = c.attention_dim; t.K = c.attention_dim; t.w_bf16 = 1;
+    e->cur.a16 = c.weight_dtype != M3_F32 && c.bf16_activations >= 0 && c.ep_world_size <= 1 && !c.debug_taps && c.embed_dim == c.attention_dim &&
+                 (c.embed_linear_units % 128) == 0 && (c.hidden_units % 128) == 0 && gemm_bf16w_uses_tiled(t);
+  }
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
   const int S = e->cur.S, D = c.attention_dim, De = c.embed_dim;
 
@@ -674,6 +704,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     g.A = pl.x; g.lda = D; g.W = e->out_linear.w; g.bias = e->out_linear.b; g.Y = logits; g.ldy = c.output_dim;
     g.M = S; g.N = c.output_dim; g.K = D;
     g.ln_wsum = e->out_linear.wsum; g.ln_eps = 1e-12f;       // after_norm is folded into out_linear
+    if (e->cur.a16) { g.A = (const float*)pl.xb; g.a_bf16 = 1; }
     add_gemm(e, "logits", g);
     const float* ob = e->output_bias;
     const int V = c.output_dim;
@@ -684,6 +715,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
   e->cur.buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
+  if (e->cur.a16) e->cur.buffers["xb"] = Buf{pl.xb, (size_t)S * D * 2};
   e->cur.buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
   e->cur.buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 

@@ -30,6 +30,13 @@ static int tiled_min_rows() {
 
 constexpr int gemm16_group_steps(int MT, int NW) { return NW == 16 ? 2 : (MT == 4 ? 2 : 4); }
 
+// long batches: LDS-tiled kernel, when there are enough 64 x 64 tiles to occupy the chip
+bool gemm_bf16w_uses_tiled(const GemmParams& p) {
+  const bool glu = p.act == ACT_GLU;
+  return p.M >= tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_bf16w_tiled_supports(p) &&
+         p.mode != GEMM_A_CONCAT2 && p.ln_gamma == nullptr;
+}
+
 template <int MT, bool GLU, int NW, bool CONV, bool LN, int NBUF>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16w_kernel(const GemmParams p) {
   constexpr int NT = GLU ? 2 : 1;
@@ -271,9 +278,8 @@ int launch_gemm_bf16w(const GemmParams& pin, hipStream_t stream) {
   if (ln) M3_REQUIRE(p.mode == GEMM_A_PLAIN && p.K <= 2047, "gemm_bf16w: LayerNorm needs plain A with K < 2048");
   M3_REQUIRE(!(ln && p.mask_in) || p.ln_wbeta, "gemm_bf16w: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm_bf16w: mask needs row_len");
-  // long batches: LDS-tiled kernel, when there are enough 64 x 64 tiles to occupy the chip
-  if (p.M >= tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_bf16w_tiled_supports(p))
-    return launch_gemm_bf16w_tiled(p, stream);
+  if (gemm_bf16w_uses_tiled(p)) return launch_gemm_bf16w_tiled(p, stream);
+  M3_REQUIRE(!p.a_bf16 && !p.y_bf16 && p.Yb == nullptr, "gemm_bf16w: bf16 activations are a feature of the tiled kernel");
   const int Nout = glu ? p.N / 2 : p.N;
   int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
   while (mt < 4 && 16 * mt < p.M && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) > 512) mt *= 2;

@@ -37,14 +37,17 @@ constexpr int tiled_lds_bytes(int BM, int BN, int BK) {
 //   2: A = H (bf16, no conversion while staging), W2 in the plan's slice-major layout or [D][F], fp32 rows out.
 // W8 (grouped forms only): W holds fp8 e4m3 with a per-output-row scale (p.w_scale); the staging threads dequantise it to
 // bf16 on the way into LDS (exact) and the scale is applied to the accumulator in the epilogue.
-template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN, int GRP, bool W8 = false>
+// A16: the A operand is already bf16 in memory (activation copies written by the producing kernels in the 16-bit modes:
+// half the A traffic, which is what bounds these GEMMs); LayerNorm statistics are then taken from the bf16 values, i.e.
+// from exactly the numbers the MFMA multiplies.  GRP = 2 implies A16.
+template <int TBM, int TBN, int TBK, bool GLU, bool CONV, bool LN, int GRP, bool W8 = false, bool A16IN = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmParams p) {
   static_assert(GRP == 0 || (!GLU && !CONV && !LN), "grouped form is a plain GEMM");
   static_assert(!W8 || GRP != 0, "fp8 weights: grouped expert GEMMs only");
   constexpr int T_LD = TBK + 8;                     // bf16 elements per LDS row (144 / 272 B: conflict-free 16-B reads)
   constexpr int C_LD = TBN + 4;                     // fp32 elements per row of the epilogue image
   constexpr int MT = TBM / 32, NT = TBN / 32;       // 16x16 MFMA tiles per wave (wave tile = TBM/2 x TBN/2)
-  constexpr bool A16 = GRP == 2;                    // A operand already bf16 (16-B chunks of 8 elements)
+  constexpr bool A16 = GRP == 2 || A16IN;           // A operand already bf16 (16-B chunks of 8 elements)
   constexpr int CA = A16 ? TBK / 8 : TBK / 4, RA = 256 / CA, JA = TBM / RA;   // A staging: chunks per row, rows per pass, passes
   constexpr int WCE = W8 ? 16 : 8, WSZ = W8 ? 1 : 2;          // W elements per 16-B chunk, bytes per element
   constexpr int CB = TBK / WCE, RB = 256 / CB, JB = TBN / RB;  // W staging: 16-B chunks per row, rows per pass, passes
@@ -124,7 +127,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       const int f2 = m % p.conv_F2;
       const int t2 = (m / p.conv_F2) % p.conv_T2;
       const int b = m / (p.conv_F2 * p.conv_T2);
-      aptr[j] = p.A + ((size_t)(b * p.conv_T1 + 2 * t2) * p.conv_F1 + 2 * f2) * p.conv_C + 4 * ac;
+      const size_t e0 = ((size_t)(b * p.conv_T1 + 2 * t2) * p.conv_F1 + 2 * f2) * p.conv_C;
+      aptr[j] = A16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(p.A) + e0 + 8 * ac) : p.A + e0 + 4 * ac;
+    } else if (A16) {
+      aptr[j] = reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(p.A) + (size_t)m * p.lda + 8 * ac);
     } else {
       aptr[j] = p.A + (size_t)m * p.lda + 4 * ac;
     }
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   f32x4 areg[JA];                                   // A16: the 16 bytes are 8 bf16, carried as they are
   u32x4 breg[JB];                                   // 16 bytes of W: 8 bf16, or 16 fp8 (W8)
   auto load_tiles = [&](int s) {
-    const int ko = A16 ? (s * TBK) / 2 : a_offset(s * TBK);       // in floats
+    const int ko = A16 ? a_offset(s * TBK) / 2 : a_offset(s * TBK);       // in floats (A16: two bf16 per float slot)
 #pragma unroll
     for (int j = 0; j < JA; ++j) areg[j] = ldg4(aptr[j] + ko);
 #pragma unroll
@@ -186,7 +192,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     for (int j = 0; j < JA; ++j) {
       const f32x4 v = areg[j];
       if (A16) {
-        *reinterpret_cast<f32x4*>(a_dst + RA * j * T_LD) = v;
+        if (LN) {                                    // statistics of the bf16 values themselves
+          const bf16x8 h8 = __builtin_bit_cast(bf16x8, v);
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)h8[e];
+            t1 += f;
+            t2 += f * f;
+          }
+          s1[j] += on * t1;
+          s2[j] += on * t2;
+        }
+        *reinterpret_cast<f32x4*>(a_dst + RA * j * T_LD) = a_zero[j] ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
         continue;
       }
       if (LN) {
@@ -238,7 +256,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   if (LN) {
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-      float t1 = group16_sum(s1[j]), t2 = group16_sum(s2[j]);   // the CA (16 or 32) lanes that staged row ar0 + RA j
+      // the CA (8 / 16 / 32) consecutive lanes that staged row ar0 + RA j: DPP butterfly of the right width
+      static_assert(CA == 8 || CA == 16 || CA == 32, "row staged by 8, 16 or 32 lanes");
+      float t1 = s1[j], t2 = s2[j];
+      t1 += dpp_mov<0xB1>(t1); t2 += dpp_mov<0xB1>(t2);       // xor 1
+      t1 += dpp_mov<0x4E>(t1); t2 += dpp_mov<0x4E>(t2);       // xor 2
+      t1 += dpp_mov<0x141>(t1); t2 += dpp_mov<0x141>(t2);     // row_half_mirror: 8 lanes
+      if (CA >= 16) {
+        t1 += dpp_mov<0x140>(t1); t2 += dpp_mov<0x140>(t2);   // row_mirror: 16 lanes
+      }
       if (CA == 32) {
         t1 += __shfl_xor(t1, 16, 64);
         t2 += __shfl_xor(t2, 16, 64);
@@ -324,7 +350,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       if (p.resid) t += res[e];
       y[e] = t;
     }
-    if (GRP == 1) {   // H in bf16 (N % 4 == 0 checked by the launcher)
+    if (p.Yb != nullptr && n + 3 < Nout) {          // bf16 copy for the next GEMM's A operand (besides the fp32 output)
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (bf16_t)y[e];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Yb) + (size_t)m * p.ldyb + n) = h;
+    }
+    if (GRP == 1 || p.y_bf16) {   // output itself in bf16 (N % 4 == 0 checked by the launcher)
       bf16x4 h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) h[e] = (bf16_t)y[e];
@@ -349,6 +381,10 @@ int init_gemm_bf16_tiled_kernels() {
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>,            \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(128, 128, 64)));   \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0>,             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(64, 64, 128)));    \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0, false, true>,  \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(128, 128, 64)));   \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0, false, true>,   \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(64, 64, 128)));
   M3_TILED_FOR_ALL(M3_TILED_ATTR)
 #undef M3_TILED_ATTR
@@ -384,11 +420,19 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
   p.m_tiles = cdiv(p.M, bm);
   p.n_tiles = glu ? cdiv(Nout, bn / 2) : cdiv(p.N, bn);
   dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);   // row tiles in groups of 8 (one per XCD), see the kernel
+  if (p.a_bf16 && !conv) M3_REQUIRE((p.lda & 7) == 0, "gemm_bf16w: bf16 A needs lda %% 8 == 0");
+  if (p.y_bf16 || p.Yb) M3_REQUIRE((Nout & 3) == 0 && (p.ldy & 3) == 0 && (p.ldyb & 3) == 0, "gemm_bf16w: bf16 output needs N %% 4 == 0");
 #define M3_TILED_LAUNCH(G_, C_, L_)                                                                                  \
   if (glu == G_ && conv == C_ && ln == L_) {                                                                         \
-    if (big)                                                                                                         \
+    if (big && p.a_bf16)                                                                                             \
+      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0, false, true>), grid, dim3(256),       \
+                         tiled_lds_bytes(128, 128, 64), stream, p);                                                  \
+    else if (big)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>), grid, dim3(256),                    \
                          tiled_lds_bytes(128, 128, 64), stream, p);                                                  \
+    else if (p.a_bf16)                                                                                               \
+      hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0, false, true>), grid, dim3(256),        \
+                         tiled_lds_bytes(64, 64, 128), stream, p);                                                   \
     else                                                                                                             \
       hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0>), grid, dim3(256),                     \
                          tiled_lds_bytes(64, 64, 128), stream, p);                                                   \

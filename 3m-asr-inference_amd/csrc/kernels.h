@@ -35,11 +35,15 @@ struct GemmParams {
   // grouped (per-expert) form of the tiled bf16 kernel: row tiles cut from acc_hist, optional row gather, slice-major W
   const int32_t* grp_acc = nullptr; int grp_E = 0; const int32_t* grp_pos = nullptr; int w_sliced = 0;
   const float* w_scale = nullptr;                         // fp8 weights (grouped forms): per-output-row scale [E][N]
+  // bf16 activation copies (16-bit modes, tiled kernel only): A given as bf16 [M][lda], Y written as bf16, and / or an
+  // additional bf16 copy Yb of the fp32 output (the residual stream stays fp32, its GEMM consumers read the copy)
+  int a_bf16 = 0, y_bf16 = 0; void* Yb = nullptr; int ldyb = 0;
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
 int launch_gemm_f32(const GemmParams& p, hipStream_t stream);   // dispatches to launch_gemm_bf16w when p.w_bf16
 int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
+bool gemm_bf16w_uses_tiled(const GemmParams& p);   // the choice launch_gemm_bf16w makes for this problem (sizes / mode only)
 // deep-K, few-tile fp32 problems (conv2 / subsampling Linear at short inputs): split-K tiled kernel + reduce (gemm_f32_splitk.hip)
 int gemm_f32_splitk_plan(const GemmParams& p, size_t* ws_bytes);   // number of K ranges (0 = not applicable) and workspace
 int launch_gemm_f32_splitk(const GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream);
@@ -100,11 +104,11 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream);
+                       hipStream_t stream, void* out_bf16 = nullptr);
 
 // ---- row-wise ops (rowops.hip) ----
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream);
+                     hipStream_t stream, void* y_bf16 = nullptr);
 int launch_softmax_top1(const float* logits, int ld, const int32_t* row_len, int rows_per_batch, int S, int E,
                         int32_t* idx, float* value, hipStream_t stream);
 int launch_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
@@ -130,13 +134,15 @@ int launch_bmm(const float* a, const float* b, float* c, int batch, int M, int N
 // ---- fused rel-pos attention (attention.hip) ----
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream);
+                            float* out, int ldo, hipStream_t stream, int out_bf16 = 0);
 
 // ---- conv module / subsampling (conv.hip) ----
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
-                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream);
+                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream,
+                          int out_bf16 = 0);
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
-                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu = 1);
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu = 1,
+                      int out_bf16 = 0);
 int launch_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D,
                 float* y, hipStream_t stream);
 int launch_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, hipStream_t stream);

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
                                                           const float* resid, float alpha,
                                                           const float* __restrict__ ln_gamma,
                                                           const float* __restrict__ ln_beta, float ln_eps,
-                                                          float* out, int S, int D) {
+                                                          float* out, int S, int D, bf16_t* out_b) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.x * 4 + wave;
   if (s >= S) return;
@@ -336,21 +336,29 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < D) stg4(out + (size_t)s * D + c, v[i]);
+    if (c < D) {
+      stg4(out + (size_t)s * D + c, v[i]);
+      if (out_b != nullptr) {                         // bf16 copy of the residual stream for the next GEMMs' A operand
+        bf16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (bf16_t)v[i][j];
+        *reinterpret_cast<bf16x4*>(out_b + (size_t)s * D + c) = h;
+      }
+    }
   }
 }
 
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream) {
+                       hipStream_t stream, void* out_bf16) {
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "moe_combine: D=%d must be a multiple of 4 (<=2048)", D);
   if (S == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(S, 4));
 #define M3_COMBINE_CASE(NV_)                                                                              \
   hipLaunchKernelGGL((moe_combine_kernel<NV_>), grid, dim3(256), 0, stream, slab, n_slices, mapping,     \
-                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D)
+                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D, (bf16_t*)out_bf16)
   if (nv <= 1) M3_COMBINE_CASE(1); else if (nv <= 2) M3_COMBINE_CASE(2); else if (nv <= 4) M3_COMBINE_CASE(4); else M3_COMBINE_CASE(8);
 #undef M3_COMBINE_CASE
   M3_LAUNCH_CHECK();

@@ -20,7 +20,7 @@ namespace m3 {
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* y, int rows, int D) {  // y may alias x (row-local)
+                                                        float* y, int rows, int D, bf16_t* yb) {  // y may alias x (row-local)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -59,18 +59,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       stg4(y + (size_t)row * D + c, o);
+      if (yb != nullptr) {                            // bf16 copy for the next GEMMs' A operand
+        bf16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (bf16_t)o[j];
+        *reinterpret_cast<bf16x4*>(yb + (size_t)row * D + c) = h;
+      }
     }
   }
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream) {
+                     hipStream_t stream, void* y_bf16) {
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "layernorm: dim=%d must be a multiple of 4 (<=2048)", D);
   if (rows == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(rows, 4));
 #define M3_LN_CASE(NV_) \
-  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D)
+  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D, (bf16_t*)y_bf16)
   if (nv <= 1) M3_LN_CASE(1); else if (nv <= 2) M3_LN_CASE(2); else if (nv <= 4) M3_LN_CASE(4); else M3_LN_CASE(8);
 #undef M3_LN_CASE
   M3_LAUNCH_CHECK();

@@ -18,7 +18,7 @@ from .plan import pack_weights
 _TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32, torch.float8_e4m3fn: _lib.FP8}
 
 
-def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False):
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -32,18 +32,21 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.ep_world_size, ec.ep_rank = cfg.ep_world_size, cfg.ep_rank
     ec.fold_pos_proj, ec.debug_taps, ec.fuse_route = int(fold_pos_proj), int(debug_taps), int(fuse_route)
     ec.log_softmax_out = int(cfg.log_softmax_out)
+    ec.bf16_activations = 0 if bf16_activations else -1
     ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "fp8": _lib.FP8}[cfg.weight_dtype]
     return ec
 
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
-                 fuse_route=False):
+                 fuse_route=False, bf16_activations=True):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
         fold_pos_proj (default on): p = linear_pos(pos_emb[:T']) of every block depends on the weights and on T' only, not
         on the input, so it is computed once when a shape is bound (constant folding) instead of in every forward.
+        bf16_activations (16-bit modes): on long batches keep GEMM-only activations and a copy of the residual stream as bf16
+        (automatic); False disables it (needed when stages are replaced from the host, e.g. ExpertParallelEncoder).
         fuse_route: 0 / False = staged route (router GEMM on cat([embed, x]) with a LayerNorm prologue that writes xn);
         1 / True = router + top-1 + index in one single-workgroup launch (S <= 256); 2 = split route (embed half of all
         routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel)."""
@@ -62,7 +65,7 @@ class Engine:
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
             table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
-        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0)
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0, bf16_activations)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())

@@ -18,6 +18,8 @@ several ranks sharing one GPU) device tensors are staged through host memory.  C
 product backend is ``HipBackend`` (libm3asr_hip.so through m3asr.ops); tests may plug the CPU oracle.
 """
 import torch
+
+from . import _lib
 import torch.distributed as dist
 
 
@@ -136,6 +138,12 @@ class ExpertParallelEncoder:
         names = eng.stage_names()
         if "blocks.0.moe_router" not in names or "router_e_all" in names:   # fused / split route engines never write xn
             raise RuntimeError("ExpertParallelEncoder needs an engine built with fuse_route=False (or ep_world_size > 1)")
+        try:
+            eng.buffer("xb")
+            raise RuntimeError("ExpertParallelEncoder needs an engine built with bf16_activations=False "
+                               "(the driver replaces the combine stage, which maintains the bf16 copy of x)")
+        except _lib.M3Error:
+            pass
         S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
         cur = 0
         with torch.cuda.stream(eng.stream):

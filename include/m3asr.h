@@ -261,6 +261,9 @@ typedef struct m3_engine_config {
   int32_t shape_cache;           /* bound (shape, buffers) sets kept besides the current one, each with its stage list and
                                   * captured hipGraph (LRU): 0 = default 7, -1 = none.  A parked binding's workspace must be
                                   * left untouched by the caller (it holds the folded positional projection). */
+  int32_t bf16_activations;      /* 16-bit modes, long batches: activations that only feed GEMMs are kept as bf16 and a bf16
+                                  * copy of the residual stream is maintained (0 = automatic, -1 = never; the expert-parallel
+                                  * host driver needs -1 because it replaces the stage that writes the copy) */
   int32_t weight_dtype;          /* M3_F32 / M3_BF16: storage of the GEMM weights (linear / point-wise conv /
                                   * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32.
                                   * M3_FP8: expert w_1 / w_2 in e4m3 with per-row scales ("...w_1.scale", "...w_2.scale"),

@@ -172,6 +172,10 @@ def _bf16_case(cfg32, seed, lengths):
     ("tiny", EncoderConfig.tiny(), [206, 57]),
     ("mid", EncoderConfig(num_blocks=3, embed_blocks=2), [206, 131, 333]),
     ("long_batch", EncoderConfig(num_blocks=2, embed_blocks=1), [400, 57, 206, 333, 120, 399, 250, 64]),   # S = 792: tiled GEMMs
+    # S = 1584 rows: every GEMM on the tiled kernel -> bf16 activation operands (xb copy of the residual stream, bf16 h1 /
+    # ctx / dw / c1 / c2), grouped tiled expert FFN
+    ("bf16_activations", EncoderConfig(num_blocks=2, embed_blocks=2),
+     [400, 57, 206, 333, 120, 399, 250, 64, 380, 390, 395, 222, 111, 345, 400, 301]),
 ])
 def test_engine_bf16_vs_fp32_oracle(name, cfg, lengths):
     eng, out, want, forced, free_taps, out_len = _bf16_case(cfg, 11, lengths)

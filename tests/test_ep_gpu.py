@@ -43,10 +43,13 @@ def test_ep_world1_bf16_equals_engine():
     for B, T in ((2, 120), (16, 400)):                      # 58 rows (slab form); 1584 rows, 1200 routed (tiled form on both sides)
         feat = torch.rand(B, T, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
         fl = torch.tensor([[T - 13 * i for i in range(B)]], dtype=torch.int32).cuda()
-        eng = Engine.from_state_dict(cfg, w)
+        eng = Engine.from_state_dict(cfg, w, bf16_activations=False)
         want = eng(feat, fl).clone()
-        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w))
+        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, bf16_activations=False))
         assert torch.equal(ep.forward(feat, fl), want)
+        if B == 16:      # the default engine keeps bf16 activation operands at this size: the EP driver must refuse it
+            with pytest.raises(RuntimeError):
+                ExpertParallelEncoder(Engine.from_state_dict(cfg, w)).forward(feat, fl)
 
 
 def _worker(rank, world, port, out_dir):
