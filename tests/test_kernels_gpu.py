@@ -260,7 +260,8 @@ def test_relpos_attention(B, T, H, dk, lens):
 
 
 # ------------------------------------------------------------------------------------------ conv pieces
-@pytest.mark.parametrize("B,T,D,K", [(1, 50, 512, 15), (2, 36, 512, 15), (2, 9, 32, 15), (1, 5, 64, 7)])
+@pytest.mark.parametrize("B,T,D,K", [(1, 50, 512, 15), (2, 36, 512, 15), (2, 9, 32, 15), (1, 5, 64, 7),
+                                     (16, 124, 512, 15), (7, 99, 512, 7), (130, 5, 64, 15)])   # >= 512 rows: 8 frames per workgroup
 def test_dwconv_ln_silu(B, T, D, K):
     z, w, b = rnd(B, T, D, seed=1), rnd(D, 1, K, seed=2, scale=0.3), rnd(D, seed=3, scale=0.1)
     g, be = rnd(D, seed=4) * 0.2 + 1.0, rnd(D, seed=5, scale=0.1)
