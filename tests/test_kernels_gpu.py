@@ -242,7 +242,10 @@ def test_fmoe_expert_position_independence():
 
 # ------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,T,H,dk,lens", [(1, 50, 8, 64, [50]), (2, 50, 8, 64, [50, 36]), (2, 37, 4, 128, [37, 5]),
-                                           (3, 9, 2, 16, [9, 6, 1]), (1, 124, 8, 64, [124])])
+                                           (3, 9, 2, 16, [9, 6, 1]), (1, 124, 8, 64, [124]),
+                                           # >= 128 workgroups of 64 queries: one 16-query tile per wave, no merge
+                                           (16, 124, 8, 64, [124, 12, 99, 124, 77, 64, 65, 1, 124, 33, 120, 124, 50, 63, 17, 101]),
+                                           (12, 70, 4, 128, [70, 66, 3, 64, 65, 70, 1, 20, 70, 70, 48, 49])])
 def test_relpos_attention(B, T, H, dk, lens):
     D = H * dk
     qkv, p = rnd(B * T, 3 * D, seed=1), rnd(T, D, seed=2)
