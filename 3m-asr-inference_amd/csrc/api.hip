@@ -42,7 +42,8 @@ MoeWorkspace carve_moe_workspace(void* base, int S, int E, int D, int F) {
 int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, const float* b1, const float* w2,
                       const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
                       float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
-                      size_t ws_bytes, hipStream_t stream, int w_bf16, const float* s1 = nullptr, const float* s2 = nullptr) {
+                      size_t ws_bytes, hipStream_t stream, int wmode /* 0 fp32, 1 bf16, 2 fp8 */, const float* s1 = nullptr,
+                      const float* s2 = nullptr) {
   M3_REQUIRE(S >= 0 && E > 0 && D > 0 && F > 0, "fmoe_expert: bad sizes S=%d E=%d D=%d F=%d", S, E, D, F);
   if (S == 0) return 0;
   MoeWorkspace w = carve_moe_workspace(ws, S, E, D, F);
@@ -50,12 +51,12 @@ int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, 
              w.bytes);
   int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
   if (rc) return rc;
-  if (w_bf16 == 2) rc = launch_expert_ffn_w8(x, D, w.pos, w.acc, S, E, D, F, w1, s1, b1, w2, s2, 0, w.slab, stream);
-  else if (w_bf16) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
+  if (wmode == 2) rc = launch_expert_ffn_w8(x, D, w.pos, w.acc, S, E, D, F, w1, s1, b1, w2, s2, 0, w.slab, stream);
+  else if (wmode) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
   else rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
   if (rc) return rc;
-  const float* rows = w_bf16 ? expert_ffn_bf16_rows(w.slab, S, E, D, F) : expert_ffn_f32_rows(w.slab, S, E, D, F);
-  const int n_slices = w_bf16 ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F);
+  const float* rows = wmode ? expert_ffn_bf16_rows(w.slab, S, E, D, F) : expert_ffn_f32_rows(w.slab, S, E, D, F);
+  const int n_slices = wmode ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F);
   return launch_moe_combine(rows, n_slices, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps,
                             y, S, D, stream);
 }

@@ -66,49 +66,29 @@ def moe_expert_workspace_size(S, E, D, F):
 
 def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None,
                    w1_scale=None, w2_scale=None):
-    """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue.
-    w1 / w2 fp32, or both bf16 (bf16 MFMA, fp32 accumulate; biases stay fp32)."""
+    """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue (gate, residual, LayerNorm).
+    The expert weights pick the kernel family: fp32; bf16 (bf16 MFMA, fp32 accumulate); e4m3 with per-row scales
+    w1_scale [E,F] / w2_scale [E,D] (dequantised to bf16 at the MFMA input).  Biases are fp32 in every mode."""
     lib = _lib.load()
-    if w1.dtype == torch.float8_e4m3fn:        # W8A16: e4m3 weights + per-row scales
-        assert w2.dtype == torch.float8_e4m3fn and w1_scale is not None and w2_scale is not None
-        S, D = x.shape
-        E, F = w1.shape[0], w1.shape[1]
-        need = moe_expert_workspace_size(S, E, D, F)
-        if workspace is None:
-            workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
-        y = torch.empty_like(x)
-        g, b, eps = ln if ln is not None else (None, None, 0.0)
-        check(lib.m3_moe_expert_ffn_fp8(_f32(x), _i32(gate_idx.reshape(-1)), _p(w1), _f32(w1_scale), _f32(b1), _p(w2),
-                                        _f32(w2_scale), _f32(b2), S, E, D, F,
-                                        _f32(gate_value.reshape(-1) if gate_value is not None else None), _f32(resid),
-                                        float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
-                                        workspace.numel(), _stream()), "m3_moe_expert_ffn_fp8")
-        return y
-    if w1.dtype == torch.bfloat16:
-        assert w2.dtype == torch.bfloat16 and w1.is_contiguous() and w2.is_contiguous()
-        S, D = x.shape
-        E, F = w1.shape[0], w1.shape[1]
-        need = moe_expert_workspace_size(S, E, D, F)
-        if workspace is None:
-            workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
-        y = torch.empty_like(x)
-        g, b, eps = ln if ln is not None else (None, None, 0.0)
-        check(lib.m3_moe_expert_ffn_bf16(_f32(x), _i32(gate_idx.reshape(-1)), _p(w1), _f32(b1), _p(w2), _f32(b2), S, E,
-                                         D, F, _f32(gate_value.reshape(-1) if gate_value is not None else None),
-                                         _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y),
-                                         _p(workspace), workspace.numel(), _stream()), "m3_moe_expert_ffn_bf16")
-        return y
+    assert w1.dtype == w2.dtype and w1.is_contiguous() and w2.is_contiguous()
     S, D = x.shape
     E, F = w1.shape[0], w1.shape[1]
-    need = moe_expert_workspace_size(S, E, D, F)
     if workspace is None:
-        workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)
+        workspace = torch.empty(max(moe_expert_workspace_size(S, E, D, F), 1), dtype=torch.uint8, device=x.device)
     y = torch.empty_like(x)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
-    check(lib.m3_moe_expert_ffn(_f32(x), _i32(gate_idx.reshape(-1)), _f32(w1), _f32(b1), _f32(w2), _f32(b2), S, E, D, F,
-                                _f32(gate_value.reshape(-1) if gate_value is not None else None), _f32(resid),
-                                float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
-                                workspace.numel(), _stream()), "m3_moe_expert_ffn")
+    gate = _f32(gate_value.reshape(-1) if gate_value is not None else None)
+    tail = (S, E, D, F, gate, _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
+            workspace.numel(), _stream())
+    xi, gi = _f32(x), _i32(gate_idx.reshape(-1))
+    if w1.dtype == torch.float8_e4m3fn:
+        assert w1_scale is not None and w2_scale is not None, "fp8 expert weights need their per-row scales"
+        check(lib.m3_moe_expert_ffn_fp8(xi, gi, _p(w1), _f32(w1_scale), _f32(b1), _p(w2), _f32(w2_scale), _f32(b2), *tail),
+              "m3_moe_expert_ffn_fp8")
+    elif w1.dtype == torch.bfloat16:
+        check(lib.m3_moe_expert_ffn_bf16(xi, gi, _p(w1), _f32(b1), _p(w2), _f32(b2), *tail), "m3_moe_expert_ffn_bf16")
+    else:
+        check(lib.m3_moe_expert_ffn(xi, gi, _f32(w1), _f32(b1), _f32(w2), _f32(b2), *tail), "m3_moe_expert_ffn")
     return y
 
 
