@@ -66,12 +66,15 @@ def encoder_param_shapes(cfg, ep_slice=True):
         sh[p + "w_2.weight"] = (d, f)
         sh[p + "w_2.bias"] = (d,)
 
-    def convmod(p, d):
+    def convmod(p, d, norm_type="layer_norm"):
         sh[p + "pointwise_conv1.weight"] = (2 * d, d, 1)
         sh[p + "pointwise_conv1.bias"] = (2 * d,)
         sh[p + "depthwise_conv.weight"] = (d, 1, K)
         sh[p + "depthwise_conv.bias"] = (d,)
         norm(p + "norm.", d)
+        if norm_type == "batch_norm":                  # nn.BatchNorm1d buffers (eval mode, convolution.py:60-75)
+            sh[p + "norm.running_mean"] = (d,)
+            sh[p + "norm.running_var"] = (d,)
         sh[p + "pointwise_conv2.weight"] = (d, d, 1)
         sh[p + "pointwise_conv2.bias"] = (d,)
 
@@ -89,7 +92,7 @@ def encoder_param_shapes(cfg, ep_slice=True):
         attn(p + "self_attn.", De, cfg.embed_heads)
         ffn(p + "feed_forward.", De, cfg.embed_linear_units)
         ffn(p + "feed_forward_macaron.", De, cfg.embed_linear_units)
-        convmod(p + "conv_module.", De)
+        convmod(p + "conv_module.", De, cfg.embed_cnn_module_norm)
         block_tail(p, De)
     sh["embed.out_linear.weight"] = (V, De)
     sh["embed.out_linear.bias"] = (V,)
@@ -109,7 +112,7 @@ def encoder_param_shapes(cfg, ep_slice=True):
         sh[p + "feed_forward.experts.w_2.weight"] = (E, D, F)
         sh[p + "feed_forward.experts.w_2.bias"] = (E, D)
         ffn(p + "feed_forward_macaron.", D, F)
-        convmod(p + "conv_module.", D)
+        convmod(p + "conv_module.", D, cfg.cnn_module_norm)
         block_tail(p, D)
     sh["out_linear.weight"] = (V, D)
     sh["out_linear.bias"] = (V,)
@@ -141,6 +144,10 @@ def make_weights(cfg, seed=0, router_std=0.5, skip_unused=True):
             t = _normal(shape, 0.1, seed, name)
         elif leaf in ("pos_bias_u", "pos_bias_v"):
             t = _uniform(shape, math.sqrt(6.0 / (shape[0] + shape[1])), seed, name)
+        elif leaf == "running_mean":
+            t = _normal(shape, 0.5, seed, name)
+        elif leaf == "running_var":
+            t = _uniform(shape, 0.5, seed, name) + 1.0
         elif ".norm" in name or name.startswith("after_norm") or "after_norm" in name:
             if leaf == "weight":
                 t = _uniform(shape, 0.5, seed, name) + 1.0

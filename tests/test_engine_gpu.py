@@ -164,6 +164,23 @@ def test_engine_longest_profile_length():
     _check(out, want, sub_len(fl.long()))
 
 
+@pytest.mark.parametrize("kw", [dict(router_with_bias=True), dict(keep_expert_output=True),
+                                dict(cnn_module_norm="batch_norm", embed_cnn_module_norm="batch_norm"),
+                                dict(router_with_bias=True, keep_expert_output=True, cnn_module_norm="batch_norm",
+                                     embed_cnn_module_norm="batch_norm", attention_heads=4, embed_heads=8, num_experts=16)])
+def test_engine_config_variants_vs_oracle(kw):
+    """The optional pieces of the reference's encoder_conf / moe_conf (router bias, un-gated expert output:
+    positionwise_feed_forward.py:169-180,258-262; BatchNorm instead of LayerNorm in the conv module: convolution.py:60-75,
+    folded into the depthwise conv by the plan packer) and other head / expert counts, ragged batch."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1, **kw)
+    w = make_weights(cfg, seed=13)
+    feat = torch.rand(3, 150, cfg.input_dim, generator=torch.Generator().manual_seed(5))
+    fl = torch.tensor([150, 96, 33], dtype=torch.int32)
+    want = encoder_forward(w, cfg, feat, fl)
+    eng, out = _run(cfg, w, feat, fl)
+    _check(out, want, sub_len(fl.long()))
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()
