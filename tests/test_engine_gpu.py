@@ -228,3 +228,9 @@ def test_front_and_back_end_cmvn_prior_logsoftmax(tmp_path):
         out = Engine(c2, packed)(feat.cuda(), fl.cuda()).cpu()
         want = ref.score(logits, log_softmax, bias)
         assert close(out[valid], want[valid]), float((out - want).abs()[valid].max())
+        # the same front / back end on a 16-bit plan (bf16 weights): within the bf16 tolerance of the fp32 score
+        c16 = EncoderConfig(**{**c2.__dict__, "weight_dtype": "bf16"})
+        p16 = add_front_back_end(pack_weights(w, c16), c16, cmvn=(mean, istd), output_bias=bias)
+        assert p16["out_linear.ln.bias"].dtype == torch.float32 and p16["cmvn.mean"].dtype == torch.float32
+        out16 = Engine(c16, p16)(feat.cuda(), fl.cuda()).cpu()
+        assert float((out16 - want).abs()[valid].max()) < 5e-2 * float(want.abs()[valid].max())
