@@ -240,6 +240,23 @@ def test_fmoe_expert_position_independence():
     assert torch.equal(y_half.cpu(), y_all.cpu()[:20])
 
 
+def test_fmoe_expert_position_independence_long_batch():
+    """The same property for the two grouped LDS-tiled GEMMs (S >= 1024): a row's result does not depend on which tile of
+    its expert it lands in, nor on the other rows of the batch."""
+    S, E, D, Fh = 2048, 32, 512, 1024
+    x = rnd(S, D, seed=1)
+    w1, b1 = rnd(E, Fh, D, seed=2, scale=D ** -0.5), rnd(E, Fh, seed=3, scale=0.1)
+    w2, b2 = rnd(E, D, Fh, seed=4, scale=Fh ** -0.5), rnd(E, D, seed=5, scale=0.1)
+    g = torch.randint(0, E, (S,), dtype=torch.int32, generator=torch.Generator().manual_seed(3))
+    args = [dev(t) for t in (w1, b1, w2, b2)]
+    y_all = ops.moe_expert_ffn(dev(x), dev(g), *args)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(4))
+    y_perm = ops.moe_expert_ffn(dev(x[perm]), dev(g[perm]), *args)
+    assert torch.equal(y_perm.cpu(), y_all.cpu()[perm])
+    y_part = ops.moe_expert_ffn(dev(x[:1500]), dev(g[:1500]), *args)       # fewer rows per expert, other tile boundaries
+    assert torch.equal(y_part.cpu(), y_all.cpu()[:1500])
+
+
 # ------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,T,H,dk,lens", [(1, 50, 8, 64, [50]), (2, 50, 8, 64, [50, 36]), (2, 37, 4, 128, [37, 5]),
                                            (3, 9, 2, 16, [9, 6, 1]), (1, 124, 8, 64, [124]),
