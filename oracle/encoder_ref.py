@@ -21,12 +21,21 @@ import torch.nn.functional as F
 from .moe_index import moe_index_ref
 
 
+def _cdiv_trunc(a, b):
+    """C integer division (truncation toward zero), for python ints and int tensors alike."""
+    if isinstance(a, torch.Tensor):
+        return torch.div(a, b, rounding_mode="trunc")
+    return int(a / b)
+
+
 def sub_len(l):
-    """MaskConv2dSample x2: (l - left_padding - 1)//stride + 1 with left_padding=2, stride=2
-    (TRTAPI++/plugin/mask_conv2d_sample_plugin/mask_conv2d_sample_kernel.cu:34-35;
-    trainer_3m_fix/layer/subsampling.py:119-137)."""
-    l = (l - 3) // 2 + 1
-    return (l - 3) // 2 + 1
+    """MaskConv2dSample x2: (l - left_padding - 1)/stride + 1 with left_padding=2, stride=2, in C `int`
+    arithmetic as the plugin computes it (TRTAPI++/plugin/mask_conv2d_sample_plugin/mask_conv2d_sample_kernel.cu:34-35).
+    The trainer's mask slicing (trainer_3m_fix/layer/subsampling.py:119-137) gives the same value for every
+    l >= 7 and for l in {3, 4}; for the degenerate l in {5, 6} the plugin's truncating division yields 1 frame
+    where the mask slicing yields 0 -- the plugin is the path being replaced, so it is the one followed."""
+    l = _cdiv_trunc(l - 3, 2) + 1
+    return _cdiv_trunc(l - 3, 2) + 1
 
 
 def cmvn(feat, lens, mean, istd):

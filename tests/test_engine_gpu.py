@@ -181,6 +181,41 @@ def test_engine_config_variants_vs_oracle(kw):
     _check(out, want, sub_len(fl.long()))
 
 
+@pytest.mark.parametrize("wdt", ["f32", "bf16"])
+def test_engine_batch_with_an_empty_utterance(wdt):
+    """An utterance shorter than the subsampling receptive field (feat_len 4 -> 0 output frames) inside a batch: all of its
+    rows are padding (their values are don't-care, attention over zero keys is NaN there); the other utterances must be
+    unaffected -- nothing but the attention keys and the depthwise-conv taps of the SAME utterance couples rows."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1, weight_dtype=wdt)
+    cfg32 = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg32, seed=21)
+    feat = torch.rand(3, 120, cfg.input_dim, generator=torch.Generator().manual_seed(7))
+    fl = torch.tensor([120, 4, 77], dtype=torch.int32)
+    eng, out = _run(cfg, w, feat, fl)
+    assert int(eng.buffer("lens", torch.int32)[1]) == 0 == int(sub_len(4))
+    keep = [0, 2]
+    eng2, out2 = _run(cfg, w, feat[keep].contiguous(), fl[keep])
+    valid = torch.arange(out.shape[1]).view(1, -1) < sub_len(fl[keep].long()).view(-1, 1)
+    assert bool(torch.isfinite(out[keep][valid]).all())
+    if wdt == "f32":
+        want = encoder_forward(w, cfg32, feat[keep], fl[keep])
+        _check(out[keep], want, sub_len(fl[keep].long()))
+    assert torch.allclose(out[keep][valid], out2[valid], rtol=1e-4, atol=1e-4)      # same rows with or without the empty one
+
+
+def test_engine_degenerate_short_utterance_follows_the_plugin_length_rule():
+    """feat_len 5/6: the MaskConv2dSample plugin's truncating division gives ONE output frame (the trainer's mask slicing
+    would give none; oracle.sub_len documents the difference) -- the engine's lens follow the plugin and the one frame
+    matches the oracle."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=22)
+    feat = torch.rand(3, 64, cfg.input_dim, generator=torch.Generator().manual_seed(8))
+    fl = torch.tensor([5, 64, 6], dtype=torch.int32)
+    eng, out = _run(cfg, w, feat, fl)
+    assert eng.buffer("lens", torch.int32).tolist() == [1, 15, 1] == sub_len(fl.long()).tolist()
+    _check(out, encoder_forward(w, cfg, feat, fl), sub_len(fl.long()))
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()
