@@ -229,6 +229,31 @@ int m3_att_masked_softmax(const float* scores, const int32_t* len, int B, int H,
                           float* out, m3_stream stream) {
   return launch_att_masked_softmax(scores, len, B, H, T1, T2, scale, out, (hipStream_t)stream);
 }
+int m3_ctc_greedy(const float* logits, const int32_t* len, int B, int T, int V, int blank, int32_t* frame_ids,
+                  int32_t* tokens, int32_t* n_tokens, m3_stream stream) {
+  return launch_ctc_greedy(logits, len, B, T, V, blank, frame_ids, tokens, n_tokens, (hipStream_t)stream);
+}
+int m3_ctc_topk(const float* logits, size_t rows, int V, int k, float* top_logp, int32_t* top_idx, m3_stream stream) {
+  return launch_ctc_topk(logits, rows, V, k, top_logp, top_idx, (hipStream_t)stream);
+}
+int m3_ctc_prefix_beam_search(const float* top_logp, const int32_t* top_idx, int T, int k, int beam, int blank,
+                              int32_t* hyp_tokens, int32_t* hyp_len, float* hyp_score, int32_t* n_hyps) {
+  return ctc_prefix_beam_search_host(top_logp, top_idx, T, k, beam, blank, hyp_tokens, hyp_len, hyp_score, n_hyps);
+}
+int m3_cat_split_cache(const void* in_cache, const void* input, int B, int cache_dim, int input_dim, void* output,
+                       void* out_cache, m3_stream stream) {
+  return launch_cat_split_cache(in_cache, input, B, cache_dim, input_dim, output, out_cache, (hipStream_t)stream);
+}
+int m3_att_stream_softmax(const float* scores, const int32_t* decode_frame_num, const int32_t* mask_idx, int B, int N,
+                          int ld, int cache_len, float scale, float* out, m3_stream stream) {
+  return launch_att_stream_softmax(scores, decode_frame_num, mask_idx, B, N, ld, cache_len, scale, out, (hipStream_t)stream);
+}
+int m3_rel_positional_encoding(const float* x, const float* pe, int pe_len, const int32_t* frame_num, int max_offset,
+                               float scale, int B, int T, int D, float* y, float* pos_emb, int32_t* frame_num_out,
+                               m3_stream stream) {
+  return launch_rel_positional_encoding(x, pe, pe_len, frame_num, max_offset, scale, B, T, D, y, pos_emb, frame_num_out,
+                                        (hipStream_t)stream);
+}
 int m3_masked_fill(const float* x, const int32_t* len, int B, int C, int T, float fill, float* y, m3_stream stream) {
   return launch_masked_fill(x, len, B, C, T, fill, y, (hipStream_t)stream);
 }

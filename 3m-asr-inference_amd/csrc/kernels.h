@@ -146,6 +146,19 @@ int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, co
 int launch_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D,
                 float* y, hipStream_t stream);
 int launch_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, hipStream_t stream);
+// decode.hip: CTC search on the logits + the streaming operators
+int launch_ctc_greedy(const float* logits, const int32_t* len, int B, int T, int V, int blank, int32_t* frame_ids,
+                      int32_t* tokens, int32_t* n_tokens, hipStream_t stream);
+int launch_ctc_topk(const float* logits, size_t rows, int V, int k, float* top_logp, int32_t* top_idx, hipStream_t stream);
+int ctc_prefix_beam_search_host(const float* top_logp, const int32_t* top_idx, int T, int k, int beam, int blank,
+                                int32_t* hyp_tokens, int32_t* hyp_len, float* hyp_score, int32_t* n_hyps);
+int launch_cat_split_cache(const void* in_cache, const void* input, int B, int cache_dim, int input_dim, void* output,
+                           void* out_cache, hipStream_t stream);
+int launch_att_stream_softmax(const float* scores, const int32_t* decode_frame_num, const int32_t* mask_idx, int B, int N,
+                              int ld, int cache_len, float scale, float* out, hipStream_t stream);
+int launch_rel_positional_encoding(const float* x, const float* pe, int pe_len, const int32_t* frame_num, int max_offset,
+                                   float scale, int B, int T, int D, float* y, float* pos_emb, int32_t* frame_num_out,
+                                   hipStream_t stream);
 int launch_depthwise_conv1d_nct(const float* x, const float* w, const float* bias, int B, int C, int T, int K,
                                 int pad, float* y, hipStream_t stream);
 

@@ -103,6 +103,12 @@ SIGNATURES = {
     "m3_cmvn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "m3_log_softmax_bias": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "m3_subsample_conv2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "m3_ctc_greedy": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "m3_ctc_topk": (_i, [_vp, _sz, _i, _i, _vp, _vp, _vp]),
+    "m3_ctc_prefix_beam_search": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "m3_cat_split_cache": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "m3_att_stream_softmax": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "m3_rel_positional_encoding": (_i, [_vp, _vp, _i, _vp, _i, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "m3_att_masked_softmax": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "m3_masked_fill": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "m3_glu": (_i, [_vp, _i, _i, _i, _vp, _vp]),

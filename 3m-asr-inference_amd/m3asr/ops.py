@@ -216,6 +216,91 @@ def log_softmax_bias(x, bias=None):
     return y
 
 
+# ---------------------------------------------------------------------------------------- CTC search on the logits
+def ctc_greedy(logits, lens=None, blank=0):
+    """encoder.py:156-180 on the device: (frame_ids (B,T), tokens (B,T) padded with -1, n_tokens (B,)) int32."""
+    lib = _lib.load()
+    B, T, V = logits.shape
+    dev = logits.device
+    ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+    tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
+    n_tokens = torch.empty(B, dtype=torch.int32, device=dev)
+    ln = None if lens is None else lens.reshape(-1).contiguous()
+    assert ln is None or ln.numel() == B
+    check(lib.m3_ctc_greedy(_f32(logits), _i32(ln), B, T, V, int(blank), _p(ids), _p(tokens), _p(n_tokens), _stream()),
+          "m3_ctc_greedy")
+    return ids, tokens, n_tokens
+
+
+def ctc_topk(logits, k):
+    """per row log_softmax + k best (value desc, index asc): (top_logp (...,k) f32, top_idx (...,k) i32)."""
+    lib = _lib.load()
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    top_logp = torch.empty(*logits.shape[:-1], k, dtype=torch.float32, device=logits.device)
+    top_idx = torch.empty(*logits.shape[:-1], k, dtype=torch.int32, device=logits.device)
+    check(lib.m3_ctc_topk(_f32(logits), rows, V, int(k), _p(top_logp), _p(top_idx), _stream()), "m3_ctc_topk")
+    return top_logp, top_idx
+
+
+def ctc_prefix_beam_search_host(top_logp, top_idx, beam, blank=0):
+    """encoder.py:232-275 over HOST (T,k) arrays of ctc_topk: [(prefix tuple, score)], best first (native host routine)."""
+    import numpy as np
+    lib = _lib.load()
+    lp = np.ascontiguousarray(top_logp, dtype=np.float32)
+    ix = np.ascontiguousarray(top_idx, dtype=np.int32)
+    T, k = lp.shape
+    assert ix.shape == (T, k)
+    toks = np.empty((beam, max(T, 1)), dtype=np.int32)
+    hlen = np.empty(beam, dtype=np.int32)
+    score = np.empty(beam, dtype=np.float32)
+    n = C.c_int32(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    if T == 0:
+        return [(tuple(), 0.0)]
+    check(lib.m3_ctc_prefix_beam_search(vp(lp), vp(ix), T, k, int(beam), int(blank), vp(toks), vp(hlen), vp(score),
+                                        C.cast(C.byref(n), C.c_void_p)), "m3_ctc_prefix_beam_search")
+    return [(tuple(int(v) for v in toks[i, :hlen[i]]), float(score[i])) for i in range(n.value)]
+
+
+# ---------------------------------------------------------------------------------------- streaming operators
+def cat_split_cache(in_cache, inp):
+    """CatSplitCache plugin: (output (B, cache+input), out_cache (B, cache)); f32 or i32 rows."""
+    lib = _lib.load()
+    assert in_cache.dtype == inp.dtype and in_cache.element_size() == 4
+    B, cd = in_cache.shape
+    idim = inp.shape[1]
+    assert inp.shape[0] == B
+    out = torch.empty(B, cd + idim, dtype=inp.dtype, device=inp.device)
+    out_cache = torch.empty(B, cd, dtype=inp.dtype, device=inp.device)
+    check(lib.m3_cat_split_cache(_p(in_cache), _p(inp), B, cd, idim, _p(out), _p(out_cache), _stream()), "m3_cat_split_cache")
+    return out, out_cache
+
+
+def att_stream_softmax(scores, decode_frame_num, mask_idx, cache_len, scale):
+    """AttStreamSoftmax plugin on scores (B, N, ld) (any leading split of N, e.g. (B, h, T, ld))."""
+    lib = _lib.load()
+    B, ld = scores.shape[0], scores.shape[-1]
+    N = scores.numel() // max(B * ld, 1)
+    out = torch.empty_like(scores)
+    check(lib.m3_att_stream_softmax(_f32(scores), _i32(decode_frame_num), _i32(mask_idx), B, N, ld, int(cache_len),
+                                    float(scale), _p(out), _stream()), "m3_att_stream_softmax")
+    return out
+
+
+def rel_positional_encoding(x, pe, scale, frame_num=None, max_offset=0):
+    """RelPositionalEncoding plugin: (x * scale, pe[off:off+T] (1,T,D)[, frame_num + T]); off = frame_num[0] or 0."""
+    lib = _lib.load()
+    B, T, D = x.shape
+    pe2 = pe.reshape(-1, D)
+    y = torch.empty_like(x)
+    pos = torch.empty(1, T, D, dtype=torch.float32, device=x.device)
+    fn_out = None if frame_num is None else torch.empty_like(frame_num)
+    check(lib.m3_rel_positional_encoding(_f32(x), _f32(pe2), pe2.shape[0], _i32(frame_num), int(max_offset), float(scale),
+                                         B, T, D, _p(y), _p(pos), _p(fn_out), _stream()), "m3_rel_positional_encoding")
+    return (y, pos) if frame_num is None else (y, pos, fn_out)
+
+
 def subsample_conv2(x, w, bias, act=_lib.ACT_RELU):
     """Conv2d(C, C, 3, stride 2) on channel-last (B,T1,F1,C) as implicit GEMM; act = ACT_RELU (fused, default) or ACT_NONE."""
     lib = _lib.load()

@@ -212,6 +212,39 @@ int m3_cmvn(const float* x, const int32_t* len, const float* mean, const float* 
             m3_stream stream);
 int m3_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, m3_stream stream);
 
+/* After the encoder: CTC search on the logits.
+ * Greedy (model/encoder.py:156-180): ids = argmax over V per frame (first maximum wins), then per utterance drop repeats
+ * and blanks over frames t < len[b] (len NULL = all T).  frame_ids [B*T] receives the per-frame argmax (also the
+ * kernel's scratch), tokens [B][T] the collapsed ids padded with -1, n_tokens [B] their counts.  All device pointers. */
+int m3_ctc_greedy(const float* logits, const int32_t* len, int B, int T, int V, int blank, int32_t* frame_ids,
+                  int32_t* tokens, int32_t* n_tokens, m3_stream stream);
+/* First beam prune of the prefix beam search on the device (encoder.py:224-231): per row log_softmax, then the k best
+ * (value desc, index asc) -> top_logp / top_idx [rows][k]. */
+int m3_ctc_topk(const float* logits, size_t rows, int V, int k, float* top_logp, int32_t* top_idx, m3_stream stream);
+/* The prefix recursion and second prune (encoder.py:232-275) -- a HOST routine over HOST copies of m3_ctc_topk's output
+ * for one utterance of T frames.  Writes at most `beam` hypotheses, best first: hyp_tokens [beam][T] (-1 padded),
+ * hyp_len [beam], hyp_score [beam] = log(p_blank + p_non_blank), *n_hyps. */
+int m3_ctc_prefix_beam_search(const float* top_logp, const int32_t* top_idx, int T, int k, int beam, int blank,
+                              int32_t* hyp_tokens, int32_t* hyp_len, float* hyp_score, int32_t* n_hyps);
+
+/* Streaming operators of the reference's plugin library (built there but not registered, trt_plugin_plus.cpp:155-156).
+ * CatSplitCachePluginDynamic (cat_split_cache_kernel.cu:30-107), 4-byte elements: output [B][cache_dim+input_dim] =
+ * in_cache ++ input, out_cache [B][cache_dim] = the last cache_dim values of output. */
+int m3_cat_split_cache(const void* in_cache, const void* input, int B, int cache_dim, int input_dim, void* output,
+                       void* out_cache, m3_stream stream);
+/* AttStreamSoftmaxPluginDynamic (att_stream_softmax_kernel.cu:28-191): scores [B][N][ld]; row (b,n) valid on
+ * [max(0, ld - decode_frame_num[b]), min(ld, min(ld, mask_idx[b]) + cache_len)); out = exp((x - max) * scale) / sum
+ * there, 0 elsewhere. */
+int m3_att_stream_softmax(const float* scores, const int32_t* decode_frame_num, const int32_t* mask_idx, int B, int N,
+                          int ld, int cache_len, float scale, float* out, m3_stream stream);
+/* RelPositionalEncodingPluginDynamic (rel_positional_encoding_kernel.cu:62-69; streaming contract :108-111):
+ * y = x * scale on (B,T,D); pos_emb [T][D] = pe[off : off+T], off = frame_num[0] (device int32 [B]; NULL = 0);
+ * frame_num_out[b] = frame_num[b] + T (distinct buffer; may be NULL).  pe has pe_len positions; max_offset is the
+ * caller's bound on frame_num[0], checked against pe_len on the host. */
+int m3_rel_positional_encoding(const float* x, const float* pe, int pe_len, const int32_t* frame_num, int max_offset,
+                               float scale, int B, int T, int D, float* y, float* pos_emb, int32_t* frame_num_out,
+                               m3_stream stream);
+
 /* small plugins */
 int m3_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
                           float* out, m3_stream stream);                 /* att_masked_softmax_plugin.cpp:84-108 */
