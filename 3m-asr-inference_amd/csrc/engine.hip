@@ -761,7 +761,7 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (!e->cur.graph_valid) {
     M3_REQUIRE(stream != nullptr, "engine_forward: graph capture needs a non-default stream");
     if (e->cur.graph_exec) {
-      hipGraphExecDestroy(e->cur.graph_exec);
+      (void)hipGraphExecDestroy(e->cur.graph_exec);
       e->cur.graph_exec = nullptr;
     }
     hipGraph_t graph = nullptr;
@@ -769,7 +769,7 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
     int rc = m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
     hipError_t ce = hipStreamEndCapture(stream, &graph);
     if (rc) {
-      if (graph) hipGraphDestroy(graph);
+      if (graph) (void)hipGraphDestroy(graph);
       return rc;
     }
     M3_CHECK_HIP(ce);

@@ -216,6 +216,26 @@ def test_engine_degenerate_short_utterance_follows_the_plugin_length_rule():
     _check(out, encoder_forward(w, cfg, feat, fl), sub_len(fl.long()))
 
 
+@pytest.mark.parametrize("lengths", [[206], [333, 64, 400, 206, 120, 399, 250, 380, 57, 390, 395, 222, 111, 345]])
+def test_engine_64_experts_vs_oracle(lengths):
+    """BASELINE configs[4] has 64 experts: one utterance (slab expert kernel, fused gate+index) and a long ragged batch
+    (moe_top1 + grouped tiled GEMMs), fp32 against the oracle; routing taps exact."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1, num_experts=64)
+    w = make_weights(cfg, seed=64)
+    feat = torch.rand(len(lengths), max(lengths), cfg.input_dim, generator=torch.Generator().manual_seed(64))
+    fl = torch.tensor(lengths, dtype=torch.int32)
+    eng, out = _run(cfg, w, feat, fl)
+    taps = {}
+    want = encoder_forward(w, cfg, feat, fl, taps)
+    _check(out, want, sub_len(fl.long()))
+    valid = torch.arange(out.shape[1]).view(1, -1) < sub_len(fl.long()).view(-1, 1)
+    for i in range(cfg.num_blocks):
+        gi = eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().view(valid.shape)
+        assert torch.equal(gi[valid], taps["blocks.%d.gate_idx" % i].view(valid.shape)[valid].to(torch.int32))
+        hist = torch.diff(eng.buffer("blocks.%d.acc_histogram" % i, torch.int32).cpu())
+        assert hist.numel() == 64 and int(hist.sum()) == int(valid.sum())
+
+
 def test_engine_rejects_bad_input():
     from m3asr._lib import M3Error
     cfg = EncoderConfig.tiny()

@@ -102,6 +102,9 @@ FP8_REL = 1e-1
 @pytest.mark.parametrize("name,cfg,lengths", [
     ("mid", EncoderConfig(num_blocks=3, embed_blocks=2), [206, 131, 333]),
     ("long_batch", EncoderConfig(num_blocks=2, embed_blocks=1), [400, 57, 206, 333, 120, 399, 250, 64, 380, 390, 395, 222, 111, 345]),
+    # BASELINE configs[4]'s expert count (64), one utterance (slab kernel) and a long batch (grouped tiled GEMMs)
+    ("e64_1x206", EncoderConfig(num_blocks=2, embed_blocks=1, num_experts=64), [206]),
+    ("e64_batch", EncoderConfig(num_blocks=2, embed_blocks=1, num_experts=64), [400, 57, 206, 333, 120, 399, 250, 64, 380, 390, 395, 222, 111, 345]),
 ])
 def test_engine_fp8_vs_fp32_oracle(name, cfg, lengths):
     w = make_weights(cfg, seed=11)
