@@ -265,11 +265,10 @@ int m3_plugin_enqueue(m3_plugin* plugin, const m3_tensor* in, int n_in, m3_tenso
       M3_REQUIRE(in[0].ndim == 3 && in[0].shape[2] == a.dim, "RelPositionalEncoding: x must be (B,T,%d)", a.dim);
       M3_REQUIRE(in[0].shape[1] < a.max_len, "RelPositionalEncoding: T'=%lld must be < max_len=%d",
                  (long long)in[0].shape[1], a.max_len);  // rel_positional_encoding_plugin.cpp:139-142
-      int rc = m3::launch_scale((const float*)in[0].data, a.scale, (float*)out[0].data, (size_t)volume(in[0]), stream);
-      if (rc) return rc;
-      M3_CHECK_HIP(hipMemcpyAsync(out[1].data, in[1].data, (size_t)in[0].shape[1] * a.dim * sizeof(float),
-                                  hipMemcpyDeviceToDevice, stream));
-      return 0;
+      // one launch for both outputs (the reference's kernel does the same, rel_positional_encoding_kernel.cu:62-69)
+      return m3::launch_rel_positional_encoding((const float*)in[0].data, (const float*)in[1].data, (int)in[1].shape[1], nullptr, 0,
+                                                a.scale, (int)in[0].shape[0], (int)in[0].shape[1], a.dim,
+                                                (float*)out[0].data, (float*)out[1].data, nullptr, stream);
     }
     case K_DUMP_TENSOR: {
       size_t es = (in[0].dtype == M3_F16 || in[0].dtype == M3_BF16) ? 2 : (in[0].dtype == M3_I8 ? 1 : 4);
