@@ -22,6 +22,8 @@
 
 namespace m3 {
 
+constexpr int kGrpRun = 4;   // row tiles of a grouped GEMM that run back to back on one XCD
+
 namespace {
 // two tile shapes: 128 x 128 x 64 when the problem has >= ~200 such tiles (MFMA-heavy: conv2), else 64 x 64 x 128 --
 // 4x the workgroups and half the k-steps, because a small GEMM is a chain of k-steps of ~1 us memory latency each
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   // tiles of one row tile run on the SAME XCD, back to back, so an A tile (fp32, the dominant traffic) is fetched from
   // HBM / Infinity Cache once instead of once per XCD; only W (small) is replicated over the L2s.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int n_tile = slot % p.n_tiles, m_tile = (slot / p.n_tiles) * 8 + xcd;
+  const int n_tile = slot % p.n_tiles;
+  // grouped: kGrpRun consecutive row tiles (~ one expert's) stay on one XCD, so the expert's W tiles are fetched once too
+  const int q_ = slot / p.n_tiles;
+  const int m_tile = GRP ? ((q_ / kGrpRun) * 8 + xcd) * kGrpRun + (q_ % kGrpRun) : q_ * 8 + xcd;
   int m0 = m_tile * TBM, m_end = p.M, expert = 0;
   if (GRP) {   // m_tile counts the row tiles of all experts in expert order: find its expert
     if (p.grp_E <= 64) {
@@ -227,13 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     }
   };
 
-  load_tiles(0);
-  store_tiles(0, 1.f);
-  __syncthreads();
-
-  for (int s = 0; s < nsteps; ++s) {
-    load_tiles(min(s + 1, nsteps - 1));             // clamped: the loads are never behind a branch
-    __builtin_amdgcn_sched_barrier(0);              // all 12 loads are in flight before the MFMA phase starts
+  auto mfma_step = [&](int s) {
     const bf16_t* a_lds = As + (s & 1) * (TBM * T_LD) + ((TBM / 2) * wm + col) * T_LD + 8 * kq;
     const bf16_t* b_lds = Bs + (s & 1) * (TBN * T_LD) + col * T_LD + 8 * kq;
 #pragma unroll
@@ -248,6 +247,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16h(a, b[nt], acc[mt][nt]);
       }
     }
+  };
+  load_tiles(0);
+  store_tiles(0, 1.f);
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    load_tiles(min(s + 1, nsteps - 1));             // clamped: the loads are never behind a branch
+    __builtin_amdgcn_sched_barrier(0);              // all 12 loads are in flight before the MFMA phase starts
+    mfma_step(s);
     __builtin_amdgcn_sched_barrier(0);
     store_tiles((s + 1) & 1, s + 1 < nsteps ? 1.f : 0.f);
     __syncthreads();
@@ -454,7 +462,7 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
   // rows per expert ~ S/E: small tiles (4x the workgroups, half the k-steps) until an expert fills 128-row tiles
   const bool big = S / E >= 192;
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
-  const int m_slots = cdiv(cdiv(S, bm) + E, 8) * 8;          // upper bound of sum_e ceil(cnt_e / bm), padded to 8 XCDs
+  const int m_slots = cdiv(cdiv(S, bm) + E, 8 * kGrpRun) * 8 * kGrpRun;   // >= sum_e ceil(cnt_e / bm), padded to 8 XCDs x kGrpRun
   GemmParams g1;
   g1.A = x; g1.lda = ldx; g1.W = (const float*)w1; g1.bias = b1; g1.Y = (float*)hbuf; g1.ldy = F;
   g1.M = S; g1.N = F; g1.K = D; g1.act = ACT_SILU;
@@ -486,7 +494,7 @@ int launch_expert_ffn_w8_tiled(const float* x, int ldx, const int32_t* pos, cons
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   const bool big = S / E >= 192;
   const int bm = big ? 128 : 64, bn = big ? 128 : 64;
-  const int m_slots = cdiv(cdiv(S, bm) + E, 8) * 8;
+  const int m_slots = cdiv(cdiv(S, bm) + E, 8 * kGrpRun) * 8 * kGrpRun;
   GemmParams g1;
   g1.A = x; g1.lda = ldx; g1.W = (const float*)w1; g1.w_scale = s1; g1.bias = b1; g1.Y = (float*)hbuf; g1.ldy = F;
   g1.M = S; g1.N = F; g1.K = D; g1.act = ACT_SILU;

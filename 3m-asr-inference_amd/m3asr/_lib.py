@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm3asr_hip.so")
+# M3ASR_LIB: development override (kernel experiments built next to the tree); the product loads the in-tree library
+LIB_PATH = os.environ.get("M3ASR_LIB") or os.path.join(_HERE, "libm3asr_hip.so")
 
 
 class M3Error(RuntimeError):
