@@ -12,7 +12,10 @@
 // the rank path: a wave matches equal expert ids with log2(E) ballots, ranks them by popcount of
 // the lower-lane mask, per-wave counts are prefix-summed over waves, and the per-expert offsets
 // come from a wavefront prefix sum (shfl_up) over the histogram.  g_i < 0 (padded frame) or
-// g_i >= E is dropped: mapping -1, not counted.  One workgroup; any S (1024-token chunks).
+// g_i >= E is dropped: mapping -1, not counted.  One workgroup (1024-token chunks) up to 4096 tokens,
+// one work-group per 1024 tokens beyond (moe_index_multi_kernel).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -171,12 +174,96 @@ __global__ __launch_bounds__(1024) void moe_index_kernel(const int32_t* gate_in,
   moe_index_body(gate, S, E, nbits, mapping, acc_hist, pos);
 }
 
+// Long batches: the same stable counting sort spread over S/1024 work-groups with no scratch memory and no
+// inter-work-group synchronisation.  Work-group b owns tokens [1024 b, 1024 (b+1)); it histograms the WHOLE gate array
+// (S * 4 bytes, L2-resident after the first work-group) into total[e] and, on the way, the part before its own chunk into
+// before[e]; acc = exclusive scan of total, and its tokens land at acc[g] + before[g] + (stable rank inside the chunk).
+// Every work-group derives the same acc; work-group 0 writes acc_hist.  Reads grow as S^2 / 1024 tokens (16 k tokens:
+// 1 MB; 262 k tokens: 268 MB from L2), against a single work-group walking the array twice.
+__global__ __launch_bounds__(1024) void moe_index_multi_kernel(const int32_t* __restrict__ gate, int S, int E, int nbits,
+                                                               int32_t* __restrict__ mapping, int32_t* __restrict__ acc_hist,
+                                                               int32_t* __restrict__ pos) {
+  __shared__ int total[kIdxMaxE];
+  __shared__ int before[kIdxMaxE];
+  __shared__ int wcnt[kIdxMaxWaves][kIdxMaxE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int my0 = blockIdx.x * 1024;
+  for (int e = tid; e < E; e += 1024) total[e] = before[e] = 0;
+  __syncthreads();
+  for (int base = 0; base < S; base += 1024) {
+    const int i = base + tid;
+    const int g = (i < S) ? gate[i] : -1;
+    const bool active = (g >= 0) && (g < E);
+    const unsigned long long m = match_expert(g, active, nbits);
+    if (active && (m & lt_mask) == 0ull) {           // the lowest lane of each group of equal ids adds the group
+      const int c = __popcll(m);
+      atomicAdd(&total[g], c);
+      if (base < my0) atomicAdd(&before[g], c);      // chunks are 1024-aligned: a whole iteration is before or not
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {                                    // exclusive scan over experts; before[e] becomes this chunk's base
+    int carry = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + lane;
+      const int v = (e < E) ? total[e] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (e < E) {
+        before[e] += carry + incl - v;
+        if (blockIdx.x == 0) acc_hist[e + 1] = carry + incl;
+      }
+      carry += __shfl(incl, 63, 64);
+    }
+    if (blockIdx.x == 0 && lane == 0) acc_hist[0] = 0;
+  }
+  // stable rank inside the chunk: earlier waves' counts + lower lanes of my wave
+  const int i = my0 + tid;
+  const int g = (i < S) ? gate[i] : -1;
+  const bool active = (g >= 0) && (g < E);
+  const unsigned long long m = match_expert(g, active, nbits);
+  const int rank = __popcll(m & lt_mask);
+  for (int e = lane; e < E; e += 64) wcnt[wave][e] = 0;
+  if (active && rank == 0) wcnt[wave][g] = __popcll(m);
+  __syncthreads();
+  if (i < S) {
+    if (active) {
+      int dst = before[g] + rank;
+      for (int w = 0; w < wave; ++w) dst += wcnt[w][g];
+      mapping[i] = dst;
+      if (pos) pos[dst] = i;
+    } else {
+      mapping[i] = -1;
+    }
+  }
+}
+
+// rows from which the multi-work-group form is used (env M3_INDEX_MULTI_MIN_ROWS; below it one work-group is faster)
+static int index_multi_min_rows() {
+  static const int v = [] {
+    const char* e = getenv("M3_INDEX_MULTI_MIN_ROWS");
+    return e ? atoi(e) : 4096;
+  }();
+  return v;
+}
+
 int launch_moe_index(const int32_t* gate_idx, int S, int E, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
                      hipStream_t stream) {
   M3_REQUIRE(E >= 1 && E <= kIdxMaxE, "moe_index: num_expert=%d out of range [1,%d]", E, kIdxMaxE);
   M3_REQUIRE(S >= 0, "moe_index: negative S");
   int nbits = 0;
   while ((1 << nbits) < E) ++nbits;
+  if (S >= index_multi_min_rows()) {
+    hipLaunchKernelGGL(moe_index_multi_kernel, dim3(cdiv(S, 1024)), dim3(1024), 0, stream, gate_idx, S, E, nbits, mapping,
+                       acc_hist, pos);
+    M3_LAUNCH_CHECK();
+    return 0;
+  }
   int threads = S >= 1024 ? 1024 : (int)align_up(S > 0 ? S : 1, 64);
   hipLaunchKernelGGL(moe_index_kernel<0>, dim3(1), dim3(threads), 0, stream, gate_idx, S, E, nbits, mapping,
                      acc_hist, pos, nullptr, nullptr, 0, nullptr, nullptr);

@@ -38,6 +38,8 @@ def close(got, want, rtol, atol):
 IDX_CASES = [
     ("one", 1, 32), ("cfg2", 50, 32), ("cfg3", 1090, 32), ("cfg5", 4400, 64), ("chunk_edge", 1024, 32),
     ("chunk_edge+1", 1025, 32), ("wide", 3000, 256), ("E1", 77, 1), ("E4", 15, 4),
+    # >= 4096 tokens: one work-group per 1024 tokens (moe_index_multi_kernel)
+    ("multi_edge", 4096, 32), ("multi", 16384 + 37, 32), ("multi_e64", 7936, 64), ("multi_wide", 5000, 256), ("multi_E1", 4097, 1),
 ]
 
 
