@@ -67,6 +67,30 @@ def test_moe_index_bit_exact(name, S, E):
         assert np.array_equal(m_ref[p], np.arange(nv)), (name, kind)       # pos is the inverse permutation
 
 
+def test_moe_index_random_sweep():
+    """40 random (S, E, routing law) draws across both forms of the kernel (one work-group below 4096 tokens, one per 1024
+    tokens above) against the numpy oracle: mapping / acc_histogram / pos bit-exact, mapping a permutation of the kept rows."""
+    rng = np.random.default_rng(2024)
+    for _ in range(40):
+        S = int(rng.choice([rng.integers(1, 4096), rng.integers(4096, 40000)]))
+        E = int(rng.choice([1, 2, 4, 8, 32, 64, 100, 256]))
+        law = rng.integers(0, 3)
+        if law == 0:
+            g = rng.integers(0, E, S)
+        elif law == 1:
+            g = np.minimum(rng.geometric(0.2, S) - 1, E - 1)
+        else:
+            g = rng.integers(-1, E, S)                      # dropped rows (padded frames)
+        gate = torch.from_numpy(g.astype(np.int32)).cuda()
+        mapping, acc, pos = ops.moe_scatter_mapping(gate, E)
+        want_map, want_acc = moe_index_ref(g.astype(np.int32), E)
+        assert np.array_equal(mapping.cpu().numpy(), want_map), (S, E, law)
+        assert np.array_equal(acc.cpu().numpy(), want_acc), (S, E, law)
+        kept = int(want_acc[-1])
+        assert np.array_equal(want_map[pos.cpu().numpy()[:kept]], np.arange(kept)), (S, E, law)   # pos = mapping^-1
+        assert np.array_equal(np.sort(mapping.cpu().numpy()[g >= 0]), np.arange(kept))
+
+
 @pytest.mark.parametrize("S,D", [(50, 512), (1090, 512), (4400, 512), (333, 32), (7, 4)])
 def test_local_scatter_gather_bit_exact(S, D):
     rng = np.random.default_rng(S + D)
