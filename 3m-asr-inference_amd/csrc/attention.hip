@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
                                                               const float* __restrict__ pos_u,
                                                               const float* __restrict__ pos_v,
                                                               const int32_t* __restrict__ row_len, int T, int D,
-                                                              float scale, float* __restrict__ out, int ldo, int out_bf16) {
+                                                              float scale, float* __restrict__ out, int ldo, int out_bf16,
+                                                              const int32_t* __restrict__ row0) {
   constexpr int KS = DK / 16;
   __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
   __shared__ float mo[4][16][DK + 1];   // per-wave partial O
@@ -34,9 +35,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
   float (*ps)[20] = ps_all[wave];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
   const int len = min(row_len ? row_len[b] : T, T);
-  const size_t brow = (size_t)b * T;
+  // packed rows (row0 != null): utterance b owns rows [row0[b], row0[b] + len) -- nothing beyond its last frame may be
+  // read (it is another utterance's) or written; padded rows: [b T, (b+1) T), frames >= len hold defined values
+  if (row0 != nullptr && q0 >= len) return;
+  const size_t brow = row0 ? (size_t)row0[b] : (size_t)b * T;
+  const int last = row0 ? len - 1 : T - 1;          // clamp for the addresses of masked lanes
+  const int q_end = row0 ? len : T;                 // query rows this utterance owns
 
-  const int qi = min(q0 + col, T - 1);
+  const int qi = min(q0 + col, last);
   const float* qrow = qkv + (brow + qi) * ldq + h * DK + 4 * kq;
   f32x4 qu[KS], qv[KS];
 #pragma unroll
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
   }
 
   for (int j0 = 16 * wave; j0 < len; j0 += 64) {
-    const int kj = min(j0 + col, T - 1);
+    const int kj = min(j0 + col, last);
     const float* krow = qkv + (brow + kj) * ldq + D + h * DK + 4 * kq;
     const float* prow = pmat + (size_t)kj * ldp + h * DK + 4 * kq;
     f32x4 kb[KS], pb[KS];
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     float vb[KS][4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const int vj = min(j0 + 4 * kq + jj, T - 1);
+      const int vj = min(j0 + 4 * kq + jj, last);
       const float* vrow = qkv + (brow + vj) * ldq + 2 * D + h * DK + col;
 #pragma unroll
       for (int n = 0; n < KS; ++n) vb[n][jj] = vrow[16 * n];
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
   for (int idx = threadIdx.x; idx < 16 * DK; idx += 256) {
     const int i = idx / DK, d = idx - i * DK;
     const int qrow = q0 + i;
-    if (qrow >= T) continue;
+    if (qrow >= q_end) continue;
     const float m_tot = fmaxf(fmaxf(mm[0][i], mm[1][i]), fmaxf(mm[2][i], mm[3][i]));
     float l_tot = 0.f, acc = 0.f;
 #pragma unroll
@@ -138,14 +144,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
 
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream, int out_bf16) {
+                            float* out, int ldo, hipStream_t stream, int out_bf16, const int32_t* row0) {
   M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
   M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0, "attention: row strides must be multiples of 4");
   dim3 grid(cdiv(T, 16), H, B);
   const int D = H * dk;
 #define M3_ATT_CASE(DK_)                                                                                   \
   hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
-                     pos_v, row_len, T, D, scale, out, ldo, out_bf16)
+                     pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0)
   switch (dk) {
     case 16: M3_ATT_CASE(16); break;
     case 32: M3_ATT_CASE(32); break;

@@ -22,10 +22,28 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, int T,
-                                                              int D, int K, float* __restrict__ out, int out_bf16) {
+                                                              int D, int K, float* __restrict__ out, int out_bf16,
+                                                              const int32_t* __restrict__ pad_of,
+                                                              const int32_t* __restrict__ row0,
+                                                              const int32_t* __restrict__ row_len) {
   __shared__ float red[2][16];
   const int row = blockIdx.x;
-  const int b = row / T, t = row % T;
+  // padded rows: row = b T + t.  Packed rows (pad_of != null): row p is frame pad_of[p] = b T + t of the padded layout
+  // (-1 past the last packed row P); utterance b owns rows [row0[b], row0[b] + len).  The reference runs the conv on the
+  // padded batch, where the frames len <= tt < T hold the constant row pointwise_conv1 produces from a zeroed input
+  // (masked_fill before the conv module, convolution.py:101-104): the packed layout keeps one copy of it at row P
+  // (written by the pw1 GEMM with rows >= P masked), and tt < 0 or tt >= T are the conv's zero padding as before.
+  int b = row / T, t = row % T, len = T;
+  size_t r0 = (size_t)b * T, rpad = 0;
+  if (pad_of != nullptr) {
+    const int pr = pad_of[row];
+    if (pr < 0) return;
+    b = pr / T;
+    t = pr - b * T;
+    len = row_len[b];
+    r0 = (size_t)row0[b];
+    rpad = (size_t)row0[gridDim.x / T];               // P = row0[B]
+  }
   const int pad = (K - 1) / 2;
   const int c = threadIdx.x * 4;
   const bool live = c < D;
@@ -41,7 +59,8 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
         const int k = min(k0 + kk, K - 1);
         const int tt = t + k - pad;
         on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
-        zz[kk] = ldg4(z + ((size_t)b * T + min(max(tt, 0), T - 1)) * D + c);
+        const int tc = min(max(tt, 0), T - 1);
+        zz[kk] = ldg4(z + (tc < len ? r0 + tc : rpad) * D + c);
         ww[kk] = ldg4(w_kc + (size_t)k * D + c);
       }
 #pragma unroll
@@ -93,7 +112,8 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
 }
 
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
-                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16) {
+                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16,
+                          const int32_t* pad_of, const int32_t* row0, const int32_t* row_len) {
   M3_REQUIRE((D & 3) == 0 && D <= 4096, "dwconv: channels=%d must be a multiple of 4 (<=4096)", D);
   M3_REQUIRE((K & 1) == 1, "dwconv: kernel size %d must be odd (non-causal)", K);
   const int rows = B * T;
@@ -101,10 +121,10 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
   const int threads = (int)align_up(D / 4, 64);
   if (K <= 15)
     hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16);
+                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len);
   else
     hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16);
+                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len);
   M3_LAUNCH_CHECK();
   return 0;
 }

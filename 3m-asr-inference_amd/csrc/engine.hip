@@ -81,6 +81,7 @@ struct m3_engine {
     void* ws = nullptr; size_t ws_bytes = 0;
     float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
+    bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
     std::vector<Stage> stages;
     std::unordered_map<std::string, Buf> buffers;
     int n_kernels = 0;
@@ -226,8 +227,16 @@ struct Plan {
   float* splitk; size_t splitk_bytes;   // split-K partials of conv2 / subsampling Linear (fp32 plans, short inputs)
   float* taps;                          // [n_blocks_total][S][D] when debug_taps
   float* pfold;                         // [n_blocks_total][Tp][D] when fold_pos_proj
+  // packed ragged batches: row plan, padded staging of the subsamplers' output, packed logits
+  int32_t *row0, *pad_of; float* xpad; void* xbpad; float* lpk;
   size_t bytes;
 };
+
+// the blocks run on packed rows: B > 1 (or forced), one rank, no per-block taps (they are read as (B, T', D)), staged route
+bool use_packed_rows(const m3_engine_config& c, int B) {
+  if (c.packed_rows < 0 || (c.packed_rows == 0 && B <= 1)) return false;
+  return c.ep_world_size <= 1 && !c.debug_taps && c.fuse_route == 0 && B <= 1024;
+}
 
 Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   Plan p;
@@ -272,6 +281,14 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   }
   p.taps = c.debug_taps ? cv.take<float>((size_t)(c.num_blocks + c.embed_blocks) * S * D) : nullptr;
   p.pfold = nullptr;
+  p.row0 = p.pad_of = nullptr; p.xpad = p.lpk = nullptr; p.xbpad = nullptr;
+  if (use_packed_rows(c, B)) {
+    p.row0 = cv.take<int32_t>(B + 1);
+    p.pad_of = cv.take<int32_t>(S);
+    p.xpad = cv.take<float>((size_t)S * D);
+    p.xbpad = cv.take<uint16_t>((size_t)S * D);
+    p.lpk = cv.take<float>((size_t)S * c.output_dim);
+  }
   p.bytes = cv.off;
   return p;
 }
@@ -314,16 +331,31 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   add_gemm(e, pfx + "conv2", g);
   // Linear(C*F2 -> D) on the (f, c)-ordered flatten, with the positional-encoding scale sqrt(D)
   // (rel_positional_encoding_kernel.cu:62-69) folded into the epilogue.
+  // packed ragged batch: the subsampler works on the padded (B, T) input; its rows are packed right after it
+  const bool packed = e->cur.packed;
   GemmParams l;
-  l.A = c2; l.lda = F2 * D; l.W = w.out.w; l.bias = w.out.b; l.Y = xout; l.ldy = D;
+  l.A = c2; l.lda = F2 * D; l.W = w.out.w; l.bias = w.out.b; l.Y = packed ? pl.xpad : xout; l.ldy = D;
   l.M = B * T2; l.N = D; l.K = F2 * D; l.alpha = sqrtf((float)D);
   l.a_bf16 = a16;
-  if (a16) { l.Yb = pl.xb; l.ldyb = D; }
+  if (a16) { l.Yb = packed ? pl.xbpad : pl.xb; l.ldyb = D; }
   add_gemm(e, pfx + "linear", l);
+  if (packed) {
+    const float* xpad = pl.xpad; const void* xbpad = pl.xbpad; void* xb = pl.xb; const int32_t* pad_of = pl.pad_of;
+    const int S = B * T2;
+    add_stage(e, pfx + "pack", a16 ? 2 : 1, [=](hipStream_t s) {
+      if (int rc = launch_local_gather(xpad, pad_of, S, D * 4, xout, s)) return rc;
+      return a16 ? launch_local_gather(xbpad, pad_of, S, D * 2, xb, s) : 0;
+    });
+  }
 }
 
 static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, int D, int F, int H, int K, bool cnn_ln,
                         bool moe, int layer, int tap_index, const Plan& pl) {
+  // every GEMM of a block is row-wise over the S rows of the batch: packed batches pass the live-row count
+  auto add_gemm = [&](m3_engine* e_, const std::string& name, GemmParams g, bool fp32_weights = false) {
+    if (e_->cur.packed) g.m_dev = pl.row0 + e_->cur.B;
+    ::add_gemm(e_, name, g, fp32_weights);
+  };
   const m3_engine_config& c = e->cfg;
   const int B = e->cur.B, Tp = e->cur.Tp, S = e->cur.S;
   float* x = pl.x;
@@ -336,6 +368,15 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   void* xb = pl.xb;
   auto from_xb = [&](GemmParams& g) { if (a16) { g.A = (const float*)xb; g.a_bf16 = 1; } };
   auto also_xb = [&](GemmParams& g) { if (a16) { g.Yb = xb; g.ldyb = D; } };
+  // packed ragged batch: rows [0, P) are the valid frames of all utterances back to back, P = row0[B] on the device;
+  // row-wise kernels skip the tiles beyond P, attention and the depthwise conv find their utterance through row0 / pad_of
+  const bool packed = e->cur.packed;
+  const int32_t* row0 = packed ? pl.row0 : nullptr;
+  const int32_t* pad_of = packed ? pl.pad_of : nullptr;
+  const int32_t* pdev = packed ? pl.row0 + B : nullptr;
+  // "frame t of utterance b is padding" for the gate: padded layout (lens, T'), packed layout one run of P rows
+  const int32_t* live_len = packed ? pdev : lens;
+  const int live_rpb = packed ? S : Tp;
   {  // x += 0.5 * FFN_macaron(LN(x))
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.mac1.w; g.bias = w.mac1.b; g.Y = pl.h1; g.ldy = F; g.M = S; g.N = F; g.K = D;
@@ -363,7 +404,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
-      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16);
+      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0);
     });
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
@@ -375,18 +416,20 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     GemmParams g;
     g.A = x; g.lda = D; g.W = w.pw1.w; g.bias = w.pw1.b; g.Y = pl.glu; g.ldy = D; g.M = S; g.N = 2 * D; g.K = D;
     g.ln_wsum = w.pw1.wsum; g.ln_wbeta = w.pw1.wbeta; g.ln_eps = eps; g.act = ACT_GLU;   // norm_conv folded into pw1
-    g.row_len = lens; g.rows_per_batch = Tp; g.mask_in = 1;
+    // padded frames enter the conv module as zeros (convolution.py:101-104); packed: the rows >= P are "padding", and
+    // row P thereby receives the constant a zeroed frame produces -- the depthwise conv reads it for taps len <= t < T'
+    g.row_len = live_len; g.rows_per_batch = live_rpb; g.mask_in = 1;
     from_xb(g);
     add_gemm(e, pfx + "conv.pw1_glu", g);
     const float* glu = pl.glu; float* dw = pl.dw;
     const float* dww = w.dw_w; const float* dwb = w.dw_b;
     const float* ng = cnn_ln ? w.n_cnn.g : nullptr; const float* nb = cnn_ln ? w.n_cnn.b : nullptr;
     add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
-      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16);
+      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16, pad_of, row0, lens);
     });
     GemmParams h;
     h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
-    h.row_len = lens; h.rows_per_batch = Tp; h.mask_out = 1; h.resid = x; h.ldr = D;
+    h.row_len = live_len; h.rows_per_batch = live_rpb; h.mask_out = 1; h.resid = x; h.ldr = D;
     h.a_bf16 = a16; also_xb(h);
     add_gemm(e, pfx + "conv.pw2", h);
   }
@@ -429,7 +472,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       r.resid = pl.eall + (size_t)layer * E; r.ldr = c.num_blocks * E;
       add_gemm(e, pfx + "moe_router", r, true);
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
-        return launch_moe_gate_index(rl, Etot, lens, Tp, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
+        return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
       });
       add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
         return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
@@ -460,11 +503,11 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch (a single workgroup: right for a
       // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
-        return launch_moe_gate_index(rl, Etot, lens, Tp, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
+        return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
       });
     } else {
       add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
-        return launch_softmax_top1(rl, Etot, lens, Tp, S, Etot, gidx, gval, s);
+        return launch_softmax_top1(rl, Etot, live_len, live_rpb, S, Etot, gidx, gval, s);
       });
       add_stage(e, pfx + "moe_local.index", 1, [=](hipStream_t s) {
         return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
@@ -653,6 +696,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     e->cur.a16 = c.weight_dtype != M3_F32 && c.bf16_activations >= 0 && c.ep_world_size <= 1 && !c.debug_taps && c.embed_dim == c.attention_dim &&
                  (c.embed_linear_units % 128) == 0 && (c.hidden_units % 128) == 0 && gemm_bf16w_uses_tiled(t);
   }
+  e->cur.packed = use_packed_rows(c, B);
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
   const int S = e->cur.S, D = c.attention_dim, De = c.embed_dim;
 
@@ -660,6 +704,10 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   {
     int32_t* lens = pl.lens;
     add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); });
+    if (e->cur.packed) {   // row plan of the packed layout: first row of every utterance, packed -> padded row map
+      int32_t* row0 = pl.row0; int32_t* pad_of = pl.pad_of;
+      add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s); });
+    }
   }
   // ---- p = linear_pos(pe[:T']) for all blocks at once (attention.py:345; input-independent, so with
   //      fold_pos_proj it is computed once per bound shape instead of once per forward) ----
@@ -705,18 +753,29 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     g.M = S; g.N = c.output_dim; g.K = D;
     g.ln_wsum = e->out_linear.wsum; g.ln_eps = 1e-12f;       // after_norm is folded into out_linear
     if (e->cur.a16) { g.A = (const float*)pl.xb; g.a_bf16 = 1; }
+    float* lout = logits;
+    if (e->cur.packed) {   // packed rows -> packed logits; the (B, T', V) output is filled from them at the end
+      lout = pl.lpk;
+      g.Y = lout;
+      g.m_dev = pl.row0 + B;
+    }
     add_gemm(e, "logits", g);
     const float* ob = e->output_bias;
     const int V = c.output_dim;
     if (c.log_softmax_out) {
-      add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(logits, ob, logits, (size_t)S, V, s); });
+      add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(lout, ob, lout, (size_t)S, V, s); });
     }   // without log-softmax a prior is folded into out_linear's bias when the plan is packed (plan.py)
+    if (e->cur.packed) {
+      const int32_t* row0 = pl.row0;
+      add_stage(e, "unpack", 1, [=](hipStream_t s) { return launch_unpack_rows(lout, row0, B, Tp, V, logits, s); });
+    }
   }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
   e->cur.buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
   if (e->cur.a16) e->cur.buffers["xb"] = Buf{pl.xb, (size_t)S * D * 2};
   e->cur.buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
+  if (e->cur.packed) e->cur.buffers["row0"] = Buf{pl.row0, (size_t)(B + 1) * 4};
   e->cur.buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 
   return (int)e->cur.stages.size();

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   }
   const int n0 = n_tile * 16;
   const int m0 = m_tile * (16 * MT);
+  if (p.m_dev != nullptr && m0 > *p.m_dev) return;   // packed ragged batch: no live row in this tile
   const int ln_k0 = p.ln_on_a2 ? p.K1 : 0;             // first K index the LayerNorm applies to
   const int Kl = p.K - ln_k0;                          // LayerNorm row width
 

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16w_kernel(const GemmParams p)
   }
   const int n0 = n_tile * 16;
   const int m0 = m_tile * (16 * MT);
+  if (p.m_dev != nullptr && m0 > *p.m_dev) return;   // packed ragged batch: no live row in this tile
 
   const float* arow[MT];
   bool a_zero[MT];

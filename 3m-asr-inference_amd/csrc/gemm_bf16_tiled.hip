@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       if (e == p.grp_E) return;
       expert = e;
     }
-  } else if (m_tile >= p.m_tiles) {
-    return;                                         // padding of the last group of 8 row tiles
+  } else if (m_tile >= p.m_tiles || (p.m_dev != nullptr && m0 > *p.m_dev)) {
+    return;                                         // padding of the last group of 8 row tiles / no live row (packed batch)
   }
   const int n0 = n_tile * OUTW;
 

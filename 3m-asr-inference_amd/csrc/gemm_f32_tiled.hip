@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const GemmParams
   const int n_tile = slot % p.n_tiles, m_tile = (slot / p.n_tiles) * 8 + xcd;
   if (m_tile >= p.m_tiles) return;                  // padding of the last group of 8 row tiles (whole workgroup exits)
   const int m0 = m_tile * TBM, m_end = p.M;
+  if (p.m_dev != nullptr && m0 > *p.m_dev) return;   // packed ragged batch: no live row in this tile
   const int n0 = n_tile * OUTW;
 
   // first W-tile row of accumulator tile nt of this wave; GLU: tile rows [0, TBN/2) value, [TBN/2, TBN) gate columns

@@ -38,6 +38,9 @@ struct GemmParams {
   // bf16 activation copies (16-bit modes, tiled kernel only): A given as bf16 [M][lda], Y written as bf16, and / or an
   // additional bf16 copy Yb of the fp32 output (the residual stream stays fp32, its GEMM consumers read the copy)
   int a_bf16 = 0, y_bf16 = 0; void* Yb = nullptr; int ldyb = 0;
+  // packed ragged batches: device-side count of live rows; work-groups whose first row lies beyond it exit (the row AT
+  // the count is still computed: it carries the conv module's pad-frame constant, see dwconv_ln_silu_kernel)
+  const int32_t* m_dev = nullptr;
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
@@ -134,12 +137,16 @@ int launch_bmm(const float* a, const float* b, float* c, int batch, int M, int N
 // ---- fused rel-pos attention (attention.hip) ----
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream, int out_bf16 = 0);
+                            float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr);
 
 // ---- conv module / subsampling (conv.hip) ----
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream,
-                          int out_bf16 = 0);
+                          int out_bf16 = 0, const int32_t* pad_of = nullptr, const int32_t* row0 = nullptr,
+                          const int32_t* row_len = nullptr);
+// packed (padding-free) rows of a ragged batch (rowops.hip): plan from the valid lengths; padded output from packed rows
+int launch_pack_plan(const int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream);
+int launch_unpack_rows(const float* in, const int32_t* row0, int B, int T, int n, float* out, hipStream_t stream);
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
                       const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu = 1,
                       int out_bf16 = 0);

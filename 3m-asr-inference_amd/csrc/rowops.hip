@@ -424,6 +424,59 @@ int launch_subsample_lens(const int32_t* len_in, int B, int32_t* len_out, hipStr
   return 0;
 }
 
+// ---------------------------------------------------------------- packed (padding-free) row plan of a ragged batch
+// len [B] valid frames per utterance (<= T) -> row0 [B+1] exclusive prefix (row0[B] = P, the packed row count) and
+// pad_of [B*T]: packed row p -> its row b*T + t in the padded layout, -1 for p >= P.  One work-group.
+__global__ __launch_bounds__(256) void pack_plan_kernel(const int32_t* __restrict__ len, int B, int T,
+                                                        int32_t* __restrict__ row0, int32_t* __restrict__ pad_of) {
+  __shared__ int start[1025];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < B; ++b) {
+      start[b] = run;
+      run += min(max(len[b], 0), T);
+    }
+    start[B] = run;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b <= B; b += blockDim.x) row0[b] = start[b];
+  const int P = start[B];
+  for (int i = threadIdx.x; i < B * T; i += blockDim.x) {
+    const int b = i / T, t = i - b * T;
+    if (t < start[b + 1] - start[b]) pad_of[start[b] + t] = i;
+    if (i >= P) pad_of[i] = -1;          // disjoint from the writes above (those go to rows < P)
+  }
+}
+int launch_pack_plan(const int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream) {
+  M3_REQUIRE(B > 0 && B <= 1024 && T > 0, "pack_plan: batch %d out of range [1,1024]", B);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), 0, stream, len, B, T, row0, pad_of);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// padded (B,T,n) <- packed rows: out[b][t] = in[row0[b] + t] for t < len[b], zeros beyond.  One wave per padded row.
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ row0,
+                                                          int B, int T, int n, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= B * T) return;
+  const int b = r / T, t = r - b * T;
+  const int len = row0[b + 1] - row0[b];
+  float* dst = out + (size_t)r * n;
+  if (t < len) {
+    const float* src = in + (size_t)(row0[b] + t) * n;
+    for (int j = lane; j < n; j += 64) dst[j] = src[j];
+  } else {
+    for (int j = lane; j < n; j += 64) dst[j] = 0.f;
+  }
+}
+int launch_unpack_rows(const float* in, const int32_t* row0, int B, int T, int n, float* out, hipStream_t stream) {
+  if (B * T == 0) return 0;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, stream, in, row0, B, T, n, out);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- small strided-batched matmul (compat path only)
 // c[b] (M,N) = a[b] (M,K) . b[b] (K,N)  or  a[b] . b[b]^T with b (N,K); sa/sb = batch strides (0 = broadcast).
 __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ a, const float* __restrict__ b,

@@ -18,7 +18,7 @@ from .plan import pack_weights
 _TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32, torch.float8_e4m3fn: _lib.FP8}
 
 
-def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True):
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True, packed_rows=None):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -34,12 +34,13 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.log_softmax_out = int(cfg.log_softmax_out)
     ec.bf16_activations = 0 if bf16_activations else -1
     ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "fp8": _lib.FP8}[cfg.weight_dtype]
+    ec.packed_rows = 0 if packed_rows is None else (1 if packed_rows else -1)
     return ec
 
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
-                 fuse_route=False, bf16_activations=True):
+                 fuse_route=False, bf16_activations=True, packed_rows=None):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
@@ -65,7 +66,7 @@ class Engine:
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
             table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
-        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0, bf16_activations)
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0, bf16_activations, packed_rows)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())
@@ -174,6 +175,30 @@ class Engine:
     def run_stages(self, first, last, stream=None):
         st = stream if stream is not None else self.stream
         check(self.lib.m3_engine_run(self.handle, first, last, C.c_void_p(st.cuda_stream)), "m3_engine_run")
+
+    def packed_rows(self):
+        """True when the bound shape runs its blocks on packed (padding-free) rows: "x" / "xn" / "embed" then hold the valid
+        frames of all utterances back to back, buffer("row0", int32) [B+1] gives each utterance's first row."""
+        try:
+            self.buffer("row0", torch.int32)
+            return True
+        except _lib.M3Error:
+            return False
+
+    def rows_padded(self, name, dtype=torch.float32, fill=0):
+        """A per-row intermediate ("x", "xn", "embed", "blocks.N.gate_idx", ...) as a (B, T', width) tensor whatever the row
+        layout of the bound shape: a view for padded rows, a copy (frames past an utterance's end = `fill`) for packed rows."""
+        B, T = self._bound[0].shape[0], self._bound[0].shape[1]
+        Tp = self.output_shape(B, T)[1]
+        rows = self.buffer(name, dtype).view(B * Tp, -1)
+        if not self.packed_rows():
+            return rows.view(B, Tp, -1)
+        row0 = self.buffer("row0", torch.int32).tolist()
+        out = torch.full((B, Tp, rows.shape[1]), fill, dtype=dtype, device=rows.device)
+        for b in range(B):
+            n = row0[b + 1] - row0[b]
+            out[b, :n] = rows[row0[b]:row0[b + 1]]
+        return out
 
     def buffer(self, name, dtype=torch.float32):
         """Zero-copy view of a named intermediate inside the bound workspace."""

@@ -144,6 +144,12 @@ class ExpertParallelEncoder:
                                "(the driver replaces the combine stage, which maintains the bf16 copy of x)")
         except _lib.M3Error:
             pass
+        try:
+            eng.buffer("row0")
+            raise RuntimeError("ExpertParallelEncoder needs an engine built with packed_rows=False "
+                               "(the exchange is written for the padded (B, T') row layout)")
+        except _lib.M3Error:
+            pass
         S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
         cur = 0
         with torch.cuda.stream(eng.stream):

@@ -100,9 +100,14 @@ def balance_router(eng, cpu_weights):
         eng.stream.synchronize()
         lens = eng.buffer("lens", torch.int32)
         Bb = lens.numel()
-        emb, xn = eng.buffer("embed").view(Bb, -1, eng.cfg.embed_dim), eng.buffer("xn").view(Bb, -1, eng.cfg.attention_dim)
-        valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
-        mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
+        if Bb > 1 and eng.packed_rows():       # packed layout: the real frames are the first row0[B] rows
+            n_real = int(eng.buffer("row0", torch.int32)[Bb])
+            emb, xn = eng.buffer("embed").view(-1, eng.cfg.embed_dim)[:n_real], eng.buffer("xn").view(-1, eng.cfg.attention_dim)[:n_real]
+            mu = torch.cat([emb.mean(0), xn.mean(0)])
+        else:
+            emb, xn = eng.buffer("embed").view(Bb, -1, eng.cfg.embed_dim), eng.buffer("xn").view(Bb, -1, eng.cfg.attention_dim)
+            valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
+            mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
         w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
         w -= torch.outer(w @ mu, mu) / (mu @ mu)
         eng.run_stages(idx, idx + 1)                                              # logits with the new weights
@@ -292,7 +297,7 @@ def main():
             # expert than in fp32 and differ by a whole expert FFN.  Numeric error is therefore reported with the oracle
             # teacher-forced to the engine's expert choices, next to the fraction of identical choices.
             Tp = got.shape[1]
-            forced = {"blocks.%d.gate_idx" % i: eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().view(B, Tp, 1).clone()
+            forced = {"blocks.%d.gate_idx" % i: eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(B, Tp, 1).clone()
                       for i in range(cfg.num_blocks)}
             ref_forced = encoder_forward(weights, cfg, feat_cpu, fl_cpu, route_override=forced)
             relf = float(((got - ref_forced).abs()[vmask].max()) / ref_forced.abs()[vmask].max())

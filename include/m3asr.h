@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 2
+#define M3ASR_ABI_VERSION 3
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -301,6 +301,11 @@ typedef struct m3_engine_config {
                                   * conv2 / expert w_1, w_2 / pos_all); router, norms, biases, conv1, depthwise stay fp32.
                                   * M3_FP8: expert w_1 / w_2 in e4m3 with per-row scales ("...w_1.scale", "...w_2.scale"),
                                   * the other GEMM weights bf16 */
+  int32_t packed_rows;           /* ragged batches (B > 1): run every row-wise kernel of the blocks on the sum of the valid
+                                  * frames instead of B x T' padded rows (0 = automatic: on for B > 1 on one rank without
+                                  * debug taps / fused routing, -1 = never, 1 = also for B = 1).  The interface does not
+                                  * change: logits come back as (B, T', V), zeros past each utterance's last frame; the
+                                  * "x" / "xn" / "embed" buffers then hold packed rows ("row0" = first row per utterance) */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

@@ -160,7 +160,7 @@ def _bf16_case(cfg32, seed, lengths):
     eng = Engine.from_state_dict(cfg16, w)
     out = eng(feat.cuda(), fl.view(1, -1).cuda()).cpu()
     B, Tp = out.shape[0], out.shape[1]
-    forced = {"blocks.%d.gate_idx" % i: eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().view(B, Tp, 1).clone()
+    forced = {"blocks.%d.gate_idx" % i: eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(B, Tp, 1).clone()
               for i in range(cfg32.num_blocks)}
     free_taps = {}
     encoder_forward(w, cfg32, feat, fl, taps=free_taps)

@@ -91,7 +91,7 @@ def test_fused_and_staged_route_paths_agree():
     feat = torch.rand(2, 206, cfg.input_dim, generator=torch.Generator().manual_seed(3)).cuda()
     fl = torch.tensor([[206, 131]], dtype=torch.int32).cuda()
     a = Engine.from_state_dict(cfg, w, fuse_route=True)
-    b = Engine.from_state_dict(cfg, w, fuse_route=False)
+    b = Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False)      # same (padded) row layout for the taps
     ya, yb = a(feat, fl).clone(), b(feat, fl).clone()
     assert "blocks.0.moe_route" in a.stage_names() and "blocks.0.moe_router" in b.stage_names()
     assert a.num_kernels() < b.num_kernels()
@@ -109,7 +109,7 @@ def test_split_route_path_agrees_with_staged():
     feat = torch.rand(2, 206, cfg.input_dim, generator=torch.Generator().manual_seed(3)).cuda()
     fl = torch.tensor([[206, 131]], dtype=torch.int32).cuda()
     a = Engine.from_state_dict(cfg, w, fuse_route=2)
-    b = Engine.from_state_dict(cfg, w, fuse_route=0)
+    b = Engine.from_state_dict(cfg, w, fuse_route=0, packed_rows=False)          # same (padded) row layout for the taps
     ya, yb = a(feat, fl).clone(), b(feat, fl).clone()
     assert "router_e_all" in a.stage_names() and "router_e_all" not in b.stage_names()
     for i in range(cfg.num_blocks):
@@ -230,7 +230,7 @@ def test_engine_64_experts_vs_oracle(lengths):
     _check(out, want, sub_len(fl.long()))
     valid = torch.arange(out.shape[1]).view(1, -1) < sub_len(fl.long()).view(-1, 1)
     for i in range(cfg.num_blocks):
-        gi = eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().view(valid.shape)
+        gi = eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(valid.shape)
         assert torch.equal(gi[valid], taps["blocks.%d.gate_idx" % i].view(valid.shape)[valid].to(torch.int32))
         hist = torch.diff(eng.buffer("blocks.%d.acc_histogram" % i, torch.int32).cpu())
         assert hist.numel() == 64 and int(hist.sum()) == int(valid.sum())
@@ -257,6 +257,46 @@ def test_engine_longest_profile_shape():
     err16 = (out16 - want).abs().amax(-1)[valid] / float(want.abs()[valid].max())
     print("bf16 at 3x6100: median %.2e, 99%% %.2e, max %.2e" % (float(err16.median()), float(err16.quantile(0.99)), float(err16.max())))
     assert float(err16.quantile(0.9)) < 5e-2
+
+
+PACK_CASES = [
+    ("two_short", EncoderConfig(num_blocks=2, embed_blocks=1), [120, 77]),                       # 49 rows: skinny kernels
+    ("with_degenerate", EncoderConfig(num_blocks=2, embed_blocks=1), [64, 5, 206, 7, 33]),       # 1-frame utterances
+    ("all_full", EncoderConfig(num_blocks=1, embed_blocks=1), [97, 97, 97]),                     # no padding at all
+    ("long_ragged", EncoderConfig(num_blocks=2, embed_blocks=1),
+     [400, 57, 206, 333, 120, 399, 250, 64, 380, 390, 395, 222, 111, 345, 50, 500]),             # 1984 padded rows: tiled
+    ("e64_ragged", EncoderConfig(num_blocks=1, embed_blocks=1, num_experts=64), [333, 64, 400, 206, 120, 399, 250, 380]),
+]
+
+
+@pytest.mark.parametrize("wdt", ["f32", "bf16"])
+@pytest.mark.parametrize("name,cfg,lengths", PACK_CASES)
+def test_engine_packed_rows_equal_padded_rows(name, cfg, lengths, wdt):
+    """Ragged batches run the blocks on the packed valid frames (m3_engine_config.packed_rows, automatic for B > 1).  Every
+    kernel of a block is row-wise except attention and the depthwise conv, which see exactly the frames of their own
+    utterance either way (plus the padded layout's constant pad frame for the conv taps past the end), so the valid logits
+    must be BIT-IDENTICAL to the padded engine's; frames past an utterance's end come back as zeros."""
+    cfgd = EncoderConfig(**{**cfg.__dict__, "weight_dtype": wdt})
+    w = make_weights(cfg, seed=31)
+    feat = torch.rand(len(lengths), max(lengths), cfg.input_dim, generator=torch.Generator().manual_seed(len(lengths)))
+    fl = torch.tensor(lengths, dtype=torch.int32)
+    packed, out_p = _run(cfgd, w, feat, fl)
+    padded, out_q = _run(cfgd, w, feat, fl, packed_rows=False)
+    assert packed.packed_rows() and not padded.packed_rows()
+    out_len = sub_len(fl.long())
+    assert packed.buffer("row0", torch.int32).cpu().tolist() == [0] + torch.cumsum(out_len, 0).tolist()
+    valid = torch.arange(out_p.shape[1]).view(1, -1) < out_len.view(-1, 1)
+    assert torch.equal(out_p[valid], out_q[valid])
+    assert bool((out_p[~valid] == 0).all())
+    if wdt == "f32":
+        _check(out_p, encoder_forward(w, cfg, feat, fl), out_len)
+    # replay (hipGraph) with other lengths in the same buffers: the row plan is recomputed on the device
+    fl2 = torch.tensor(list(reversed(lengths)), dtype=torch.int32)
+    fl2[0] = max(lengths)
+    out2 = packed.infer(feat.cuda(), fl2.view(1, -1).cuda()).cpu()
+    want2 = padded.infer(feat.cuda(), fl2.view(1, -1).cuda()).cpu()
+    valid2 = torch.arange(out2.shape[1]).view(1, -1) < sub_len(fl2.long()).view(-1, 1)
+    assert torch.equal(out2[valid2], want2[valid2]) and bool((out2[~valid2] == 0).all())
 
 
 def test_engine_rejects_bad_input():

@@ -26,8 +26,8 @@ def test_ep_world1_equals_fused_engine():
     feat = torch.rand(2, 120, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
     fl = torch.tensor([[120, 77]], dtype=torch.int32).cuda()
     # the EP driver replaces the moe_local.* stages of the staged (unfused-route) engine: same kernels, same order
-    staged = Engine.from_state_dict(cfg, w, fuse_route=False)(feat, fl).clone()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False))
+    staged = Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False)(feat, fl).clone()
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False))
     assert torch.equal(ep.forward(feat, fl), staged)
     # fuse_route engines do router + top-1 + index in one launch (different summation order in the router)
     fused = Engine.from_state_dict(cfg, w, fuse_route=True)(feat, fl)
@@ -43,13 +43,13 @@ def test_ep_world1_bf16_equals_engine():
     for B, T in ((2, 120), (16, 400)):                      # 58 rows (slab form); 1584 rows, 1200 routed (tiled form on both sides)
         feat = torch.rand(B, T, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
         fl = torch.tensor([[T - 13 * i for i in range(B)]], dtype=torch.int32).cuda()
-        eng = Engine.from_state_dict(cfg, w, bf16_activations=False)
+        eng = Engine.from_state_dict(cfg, w, bf16_activations=False, packed_rows=False)
         want = eng(feat, fl).clone()
-        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, bf16_activations=False))
+        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, bf16_activations=False, packed_rows=False))
         assert torch.equal(ep.forward(feat, fl), want)
         if B == 16:      # the default engine keeps bf16 activation operands at this size: the EP driver must refuse it
             with pytest.raises(RuntimeError):
-                ExpertParallelEncoder(Engine.from_state_dict(cfg, w)).forward(feat, fl)
+                ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False)).forward(feat, fl)
 
 
 def _worker(rank, world, port, out_dir, wdt):
@@ -63,7 +63,7 @@ def _worker(rank, world, port, out_dir, wdt):
     T = 90 - 7 * rank
     feat = torch.randn(2, T, cfg.input_dim, generator=g)
     fl = torch.tensor([[T, T - 20]], dtype=torch.int32)
-    eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path
+    eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path, padded rows
     out = ExpertParallelEncoder(eng).forward(feat.cuda(), fl.cuda()).cpu()
     # reference: all experts local (fp32: the CPU oracle; bf16: the single-rank engine of the same precision, whose row
     # results are position independent)

@@ -117,7 +117,7 @@ def test_engine_fp8_vs_fp32_oracle(name, cfg, lengths):
     assert eng.weights["blocks.0.feed_forward_macaron.w_2.weight"].dtype == torch.bfloat16
     out = eng(feat.cuda(), fl.view(1, -1).cuda()).cpu()
     B, Tp = out.shape[0], out.shape[1]
-    forced = {"blocks.%d.gate_idx" % i: eng.buffer("blocks.%d.gate_idx" % i, torch.int32).cpu().view(B, Tp, 1).clone()
+    forced = {"blocks.%d.gate_idx" % i: eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(B, Tp, 1).clone()
               for i in range(cfg.num_blocks)}
     free = {}
     encoder_forward(w, cfg, feat, fl, taps=free)
@@ -159,6 +159,6 @@ def test_ep_world1_fp8_equals_engine():
     w = make_weights(cfg, seed=4)
     feat = torch.rand(2, 120, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
     fl = torch.tensor([[120, 107]], dtype=torch.int32).cuda()
-    want = Engine.from_state_dict(cfg, w)(feat, fl).clone()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w))
+    want = Engine.from_state_dict(cfg, w, packed_rows=False)(feat, fl).clone()
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False))
     assert torch.equal(ep.forward(feat, fl), want)
