@@ -65,6 +65,8 @@ def parse():
                     help="storage of the GEMM weights (bf16 = BASELINE.json configs[2]; the headline metric is f32)")
     ap.add_argument("--varlen", default="", help="LO-HI: utterance lengths drawn from U[LO,HI] frames (configs[2]: 50-500)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
+    ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
+                    help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
     return ap.parse_args()
 
 
@@ -152,8 +154,9 @@ def main():
     feat_cpu = torch.from_numpy(rng.random((B, T, cfg.input_dim), dtype=np.float32))
     feat = feat_cpu.to(dev)
     feat_len = torch.from_numpy(lengths.astype(np.int32)).view(1, B).to(dev)
+    packed = {"auto": None, "on": True, "off": False}[args.packed_rows]
     # the staged-route engine exposes xn / the router stage, which the synthetic-router calibration needs
-    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False)
+    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False, packed_rows=packed)
     if args.routing == "balanced":
         eng.bind(feat, feat_len)
         balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
@@ -161,7 +164,7 @@ def main():
     if route:                                # rebuild from the calibrated state_dict
         del eng
         torch.cuda.empty_cache()
-        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route)
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed)
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         weights = None
     eng.bind(feat, feat_len)
@@ -171,7 +174,7 @@ def main():
     # extra execution contexts: same weights, own utterance / stream / workspace / graph
     ctxs = [eng]
     for si in range(1, args.streams):
-        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=route)
+        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed)
         f2 = torch.from_numpy(np.random.default_rng(5000 + 97 * rank + si).random((B, T, cfg.input_dim), dtype=np.float32)).to(dev)
         c.bind(f2, feat_len.clone())
         ctxs.append(c)
@@ -328,7 +331,8 @@ def main():
                           "parallelism": "replicas x%d" % world, "streams_per_gpu": len(ctxs),
                           "latency_ms_one_stream": round(latency_ms, 4), "hip_graph": use_graph,
                           "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
-                          "routing": args.routing, "route_mode": ["staged", "fused", "split"][route]},
+                          "routing": args.routing, "route_mode": ["staged", "fused", "split"][route],
+                          "packed_rows": bool(B > 1 and eng.packed_rows())},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
