@@ -65,6 +65,9 @@ def parse():
                     help="storage of the GEMM weights (bf16 = BASELINE.json configs[2]; the headline metric is f32)")
     ap.add_argument("--varlen", default="", help="LO-HI: utterance lengths drawn from U[LO,HI] frames (configs[2]: 50-500)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N > 1 runs (nccl = RCCL; gloo: rehearsal of the multi-rank path "
+                         "on a box with fewer GPUs than ranks -- ranks then share devices)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
     return ap.parse_args()
@@ -125,13 +128,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    if args.dist_backend == "gloo":          # rehearsal: more ranks than devices is fine, they share
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:      # host-side weight generation / packing: do not oversubscribe the cores with N ranks x all threads
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from m3asr.config import EncoderConfig, subsampled_len
     from m3asr.weights import make_weights
@@ -196,7 +204,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
