@@ -132,30 +132,49 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
 // feat [B][T][idim] -> out [B][T1][F1][C] (channel-last), w9c [9][C] (repacked from (C,1,3,3)), ReLU.
 // Optional global CMVN folded into the read: x <- (x - mean[f]) * istd[f]   (the reference's unfinished CmvnPlugin,
 // incomplete_plugin/cmvn_plugin/cmvn_plugin.cu:17-43; builder.sh:9 passes --cmvn_file but builder.py ignores it).
+// One work-group per output row (b, t1): thread = 4 channels.  The thread's 9 x 4 weights and bias stay in registers,
+// the three input rows (CMVN applied on the way) sit in LDS and are read as broadcasts, and the work-group walks the F1
+// output columns writing C contiguous channels each -- no per-element index arithmetic, no weight reloads, 1-2 KB stores.
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ feat, const float* __restrict__ w9c,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ cmvn_mean,
                                                          const float* __restrict__ cmvn_istd, int T, int idim, int T1,
-                                                         int F1, int C, float* __restrict__ out, size_t n4, int relu, int out_bf16) {
-  const int c4n = C >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % c4n) * 4;
-    size_t rem = i / c4n;
-    const int f1 = (int)(rem % F1);
-    rem /= F1;
-    const int t1 = (int)(rem % T1);
-    const int b = (int)(rem / T1);
-    f32x4 acc = ldg4(bias + c);
-    const float* base = feat + ((size_t)b * T + 2 * t1) * idim + 2 * f1;
+                                                         int F1, int C, float* __restrict__ out, int relu, int out_bf16) {
+  extern __shared__ float xs[];                       // [3][idim]
+  const int row = blockIdx.x;                         // b * T1 + t1
+  const int b = row / T1, t1 = row - b * T1;
+  const float* src = feat + ((size_t)b * T + 2 * t1) * idim;
+  for (int i = threadIdx.x; i < 3 * idim; i += blockDim.x) {
+    float xv = src[i];
+    if (cmvn_mean != nullptr) {
+      const int f = i % idim;
+      xv = (xv - cmvn_mean[f]) * cmvn_istd[f];
+    }
+    xs[i] = xv;
+  }
+  const int c = threadIdx.x * 4;
+  const bool live = c < C;
+  f32x4 w[9], bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    bv = ldg4(bias + c);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = ldg4(w9c + (size_t)k * C + c);
+  }
+  __syncthreads();
+  if (!live) return;
+  const size_t obase = (size_t)row * F1 * C + c;
+  // short inputs: the F1 columns of a row are split over blockIdx.y so that a single utterance still fills the chip
+  const int fchunk = (F1 + gridDim.y - 1) / gridDim.y;
+  const int f_lo = blockIdx.y * fchunk, f_hi = min(F1, f_lo + fchunk);
+  for (int f1 = f_lo; f1 < f_hi; ++f1) {
+    f32x4 acc = bv;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        float xv = base[kh * idim + kw];
-        if (cmvn_mean != nullptr) xv = (xv - cmvn_mean[2 * f1 + kw]) * cmvn_istd[2 * f1 + kw];
-        const f32x4 w = ldg4(w9c + (kh * 3 + kw) * C + c);
+        const float xv = xs[kh * idim + 2 * f1 + kw];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, w[kh * 3 + kw][j], acc[j]);
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = relu ? fmaxf(acc[j], 0.f) : acc[j];
@@ -163,9 +182,9 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
       bf16x4 h;
 #pragma unroll
       for (int j = 0; j < 4; ++j) h[j] = (bf16_t)acc[j];
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + i * 4) = h;
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + obase + (size_t)f1 * C) = h;
     } else {
-      stg4(out + i * 4, acc);
+      stg4(out + obase + (size_t)f1 * C, acc);
     }
   }
 }
@@ -173,11 +192,13 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
                       const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu, int out_bf16) {
   M3_REQUIRE(T >= 3 && idim >= 3, "subsampling: input (T=%d, idim=%d) shorter than the 3x3 kernel", T, idim);
-  M3_REQUIRE((C & 3) == 0, "subsampling: channels=%d must be a multiple of 4", C);
+  M3_REQUIRE((C & 3) == 0 && C <= 1024, "subsampling: channels=%d must be a multiple of 4 (<= 1024)", C);
   const int T1 = (T - 3) / 2 + 1, F1 = (idim - 3) / 2 + 1;
-  const size_t n4 = (size_t)B * T1 * F1 * (C / 4);
-  hipLaunchKernelGGL(conv1_relu_kernel, dim3(grid1d(n4, 4096)), dim3(256), 0, stream,
-                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, n4, relu, out_bf16);
+  if (B * T1 == 0) return 0;
+  const int threads = (int)align_up(C / 4, 64);
+  const int fsplit = B * T1 >= 2048 ? 1 : (B * T1 >= 512 ? 2 : 5);
+  hipLaunchKernelGGL(conv1_relu_kernel, dim3(B * T1, fsplit), dim3(threads), 3 * idim * sizeof(float), stream,
+                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, relu, out_bf16);
   M3_LAUNCH_CHECK();
   return 0;
 }
