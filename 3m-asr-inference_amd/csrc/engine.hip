@@ -328,6 +328,7 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   g.mode = GEMM_A_CONV3X3S2; g.A = c1; g.lda = 4;
   g.conv_T1 = T1; g.conv_F1 = F1; g.conv_T2 = T2; g.conv_F2 = F2; g.conv_C = D;
   g.W = w.c2w; g.bias = w.c2b; g.Y = c2; g.ldy = D; g.M = B * T2 * F2; g.N = D; g.K = 9 * D; g.act = ACT_RELU;
+  if (e->cur.packed) g.conv_len = pl.lens;   // tiles of padded frames only: skipped (never gathered into the packed rows)
   add_gemm(e, pfx + "conv2", g);
   // Linear(C*F2 -> D) on the (f, c)-ordered flatten, with the positional-encoding scale sqrt(D)
   // (rel_positional_encoding_kernel.cu:62-69) folded into the epilogue.

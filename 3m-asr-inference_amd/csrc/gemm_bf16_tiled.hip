@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   } else if (m_tile >= p.m_tiles || (p.m_dev != nullptr && m0 > *p.m_dev)) {
     return;                                         // padding of the last group of 8 row tiles / no live row (packed batch)
   }
+  if (CONV && p.conv_len != nullptr) {
+    const int per_utt = p.conv_T2 * p.conv_F2;
+    const int b0 = m0 / per_utt, b1 = min(m0 + TBM - 1, p.M - 1) / per_utt;
+    if (b0 == b1 && (m0 - b0 * per_utt) / p.conv_F2 >= p.conv_len[b0]) return;   // every row is a padded frame
+  }
   const int n0 = n_tile * OUTW;
 
   // first W-tile row of accumulator tile nt of this wave; GLU: tile rows [0, TBN/2) value, [TBN/2, TBN) gate columns

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const GemmParams
   if (m_tile >= p.m_tiles) return;                  // padding of the last group of 8 row tiles (whole workgroup exits)
   const int m0 = m_tile * TBM, m_end = p.M;
   if (p.m_dev != nullptr && m0 > *p.m_dev) return;   // packed ragged batch: no live row in this tile
+  if (CONV && p.conv_len != nullptr) {
+    const int per_utt = p.conv_T2 * p.conv_F2;
+    const int b0 = m0 / per_utt, b1 = min(m0 + TBM - 1, p.M - 1) / per_utt;
+    if (b0 == b1 && (m0 - b0 * per_utt) / p.conv_F2 >= p.conv_len[b0]) return;   // every row is a padded frame
+  }
   const int n0 = n_tile * OUTW;
 
   // first W-tile row of accumulator tile nt of this wave; GLU: tile rows [0, TBN/2) value, [TBN/2, TBN) gate columns

@@ -41,6 +41,9 @@ struct GemmParams {
   // packed ragged batches: device-side count of live rows; work-groups whose first row lies beyond it exit (the row AT
   // the count is still computed: it carries the conv module's pad-frame constant, see dwconv_ln_silu_kernel)
   const int32_t* m_dev = nullptr;
+  // implicit conv on a packed ragged batch: valid output frames per utterance; a tile whose rows (b, t2, f2) all lie past
+  // the utterance's last frame is skipped (its output rows are never gathered into the packed layout)
+  const int32_t* conv_len = nullptr;
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
