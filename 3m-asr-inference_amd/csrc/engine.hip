@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <functional>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -82,6 +83,10 @@ struct m3_engine {
     float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
+    // fold_pos_proj: linear_pos(pe[:T']) of every block, computed once per T'.  ENGINE-owned device memory (shared by all
+    // bindings of the same T', freed with the last of them): a caller that reuses one workspace for several shapes, as a
+    // TensorRT execution context does, must not be able to overwrite it between two forwards of a revived binding
+    std::shared_ptr<float> pfold;
     std::vector<Stage> stages;
     std::unordered_map<std::string, Buf> buffers;
     int n_kernels = 0;
@@ -96,6 +101,7 @@ struct m3_engine {
   std::vector<Bound> parked;
   uint64_t use_clock = 0;
   int n_captures = 0;                                      // graphs captured so far (observability / tests)
+  std::unordered_map<int, std::weak_ptr<float>> pfold_by_tp;   // T' -> folded positional projection still in use
 };
 
 namespace {
@@ -654,7 +660,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
-  const Plan pl = make_plan(c, workspace, B, T);
+  Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----
   if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
@@ -717,9 +723,19 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams pp;
     pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
     if (c.fold_pos_proj) {
-      pp.w_bf16 = c.weight_dtype != M3_F32;
-      if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
-      M3_CHECK_HIP(hipStreamSynchronize(nullptr));
+      std::shared_ptr<float> pf = e->pfold_by_tp[Tp].lock();
+      if (!pf) {
+        float* dev = nullptr;
+        M3_CHECK_HIP(hipMalloc((void**)&dev, (size_t)Tp * nb * D * sizeof(float)));
+        pf = std::shared_ptr<float>(dev, [](float* q) { (void)hipFree(q); });
+        pp.Y = dev;
+        pp.w_bf16 = c.weight_dtype != M3_F32;
+        if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
+        M3_CHECK_HIP(hipStreamSynchronize(nullptr));
+        e->pfold_by_tp[Tp] = pf;
+      }
+      e->cur.pfold = pf;
+      pl.pbuf = pf.get();
     } else {
       add_gemm(e, "pos_all", pp);
     }

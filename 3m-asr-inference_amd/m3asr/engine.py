@@ -5,6 +5,7 @@ Plays the role of TensorRT's ICudaEngine + IExecutionContext in the reference
 memory owned by this object (torch tensors), activations in a caller-visible workspace tensor, the
 forward is one C call that replays a hipGraph.
 """
+import collections
 import ctypes as C
 
 import torch
@@ -40,7 +41,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
-                 fuse_route=False, bf16_activations=True, packed_rows=None):
+                 fuse_route=False, bf16_activations=True, packed_rows=None, max_shapes=8):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
@@ -71,8 +72,13 @@ class Engine:
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())
         self.stream = torch.cuda.Stream(device=self.device)
-        self._ws = {}          # (B, T) -> workspace; kept for the life of the engine: the native shape cache may hold a
-        self._static = {}      # parked binding whose workspace contains the folded positional projection
+        # (B, T) -> workspace / static I/O buffers, LRU-bounded like the native shape cache (current binding + 7 parked):
+        # a server fed unbucketed lengths must not keep a workspace per length ever seen.  Dropping a workspace that a
+        # parked native binding still names is harmless: a binding is revived only on an exact pointer match, everything
+        # in a workspace is rewritten by the forward, and the folded positional projection lives in engine-owned memory.
+        self.max_shapes = max(1, int(max_shapes))
+        self._ws = collections.OrderedDict()
+        self._static = collections.OrderedDict()
         self._bound = None
 
     @classmethod
@@ -97,11 +103,18 @@ class Engine:
     def workspace_size(self, B, T):
         return self.lib.m3_engine_workspace_size(self.handle, B, T)
 
+    def _lru(self, cache, key, make):
+        v = cache.get(key)
+        if v is None:
+            v = cache[key] = make()
+            while len(cache) > self.max_shapes:
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(key)
+        return v
+
     def _workspace(self, B, T):
-        ws = self._ws.get((B, T))
-        if ws is None:
-            ws = self._ws[(B, T)] = torch.empty(self.workspace_size(B, T), dtype=torch.uint8, device=self.device)
-        return ws
+        return self._lru(self._ws, (B, T), lambda: torch.empty(self.workspace_size(B, T), dtype=torch.uint8, device=self.device))
 
     def bind(self, feat, feat_len, logits=None):
         """Bind device buffers (feat (B,T,idim) f32, feat_len (1,B)/(B,) i32); returns logits tensor."""
@@ -140,13 +153,10 @@ class Engine:
         between length buckets re-captures nothing) and the shape's logits buffer is returned -- valid until the next
         infer() of the same shape."""
         B, T = int(feat.shape[0]), int(feat.shape[1])
-        st = self._static.get((B, T))
-        if st is None:
-            st = self._static[(B, T)] = (
-                torch.empty(B, T, self.cfg.input_dim, dtype=torch.float32, device=self.device),
-                torch.empty(1, B, dtype=torch.int32, device=self.device),
-                torch.empty(self.output_shape(B, T), dtype=torch.float32, device=self.device))
-        f, l, out = st
+        f, l, out = self._lru(self._static, (B, T), lambda: (
+            torch.empty(B, T, self.cfg.input_dim, dtype=torch.float32, device=self.device),
+            torch.empty(1, B, dtype=torch.int32, device=self.device),
+            torch.empty(self.output_shape(B, T), dtype=torch.float32, device=self.device)))
         with torch.cuda.stream(self.stream):
             f.copy_(feat, non_blocking=True)
             l.copy_(feat_len.reshape(1, B).to(torch.int32), non_blocking=True)

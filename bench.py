@@ -28,7 +28,17 @@ for p in (ROOT, os.path.join(ROOT, "3m-asr-inference_amd")):
 
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the execution contexts of --streams need one
 # each, so ask for 8 before the runtime initialises (a process-level runtime knob, not a machine setting)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# -- unless a profiler is preloaded: rocprofv3 initialises the runtime before this line runs and intercepts every HW
+# queue for its counter collection (see DESIGN.md "The --pmc abort"); the override is then skipped
+def _profiler_attached():
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+
+
+if not _profiler_attached():
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+else:
+    print("bench: profiler attached, GPU_MAX_HW_QUEUES left at %s" % os.environ.get("GPU_MAX_HW_QUEUES", "<default>"), file=sys.stderr)
 
 import numpy as np
 import torch

@@ -292,8 +292,9 @@ typedef struct m3_engine_config {
                                   * 2 = split route: embed half of all routers in one GEMM, x half with folded LayerNorm,
                                   *     norm_ff applied by the expert kernel (1 rank, fp32) */
   int32_t shape_cache;           /* bound (shape, buffers) sets kept besides the current one, each with its stage list and
-                                  * captured hipGraph (LRU): 0 = default 7, -1 = none.  A parked binding's workspace must be
-                                  * left untouched by the caller (it holds the folded positional projection). */
+                                  * captured hipGraph (LRU): 0 = default 7, -1 = none.  Nothing the engine needs between two
+                                  * forwards lives in the caller's workspace (the folded positional projection is
+                                  * engine-owned device memory), so one workspace may serve every shape. */
   int32_t bf16_activations;      /* 16-bit modes, long batches: activations that only feed GEMMs are kept as bf16 and a bf16
                                   * copy of the residual stream is maintained (0 = automatic, -1 = never; the expert-parallel
                                   * host driver needs -1 because it replaces the stage that writes the copy) */

@@ -152,6 +152,50 @@ def test_shape_cache_replays_graphs_across_alternating_shapes():
     assert torch.equal(out2, ref(f2.cuda(), lens[(1, 206)].view(1, -1).cuda()))
 
 
+def test_one_shared_workspace_for_every_shape_like_a_trt_execution_context():
+    """A C-ABI caller may hand m3_engine_forward ONE max-size workspace for every shape (a TensorRT execution context owns
+    one device-memory block).  Shapes A, B, A: the second A revives a parked binding on an exact (shape, pointers) match
+    after B has overwritten the whole workspace -- the folded positional projection must not have lived there (it is
+    engine-owned memory).  Checked against fresh engines, eager and graph replay, fp32 bit-identical."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=6)
+    eng = Engine.from_state_dict(cfg, w, fold_pos_proj=True)
+    g = torch.Generator().manual_seed(12)
+    shapes = [(1, 206), (2, 333), (1, 206), (3, 64), (2, 333), (1, 206)]
+    big = torch.empty(max(eng.workspace_size(b, t) for b, t in shapes), dtype=torch.uint8, device="cuda")
+    eng._workspace = lambda B, T: big                      # every shape binds the same caller-owned block
+    io = {}
+    for b, t in set(shapes):
+        feat = torch.rand(b, t, cfg.input_dim, generator=g).cuda()
+        fl = torch.tensor([[t - 11 * i for i in range(b)]], dtype=torch.int32).cuda()
+        io[(b, t)] = (feat, fl, torch.empty(eng.output_shape(b, t), device="cuda"),
+                      Engine.from_state_dict(cfg, w, fold_pos_proj=False)(feat, fl).clone())
+    for use_graph in (False, True):
+        for b, t in shapes:
+            feat, fl, out, want = io[(b, t)]
+            big.fill_(0xFF)                                # whatever the previous shape left behind
+            torch.cuda.synchronize()
+            eng.forward(feat, fl, out, use_graph=use_graph)
+            eng.stream.synchronize()
+            assert torch.equal(out, want), (use_graph, b, t)
+
+
+def test_python_side_shape_caches_are_bounded():
+    """Engine.infer on unbucketed lengths: workspaces / static I/O buffers are kept LRU-bounded (max_shapes), not one per
+    length ever seen; results stay right after evictions."""
+    cfg = EncoderConfig.tiny()
+    w = make_weights(cfg, seed=3)
+    eng = Engine.from_state_dict(cfg, w, max_shapes=3)
+    ref = Engine.from_state_dict(cfg, w)
+    g = torch.Generator().manual_seed(2)
+    for T in [40, 41, 42, 43, 44, 40, 45, 41]:
+        feat = torch.randn(1, T, cfg.input_dim, generator=g)
+        fl = torch.tensor([T], dtype=torch.int32)
+        out = eng.infer(feat, fl)
+        assert len(eng._ws) <= 3 and len(eng._static) <= 3
+        assert torch.equal(out, ref(feat.cuda(), fl.view(1, -1).cuda()))
+
+
 def test_engine_longest_profile_length():
     """The reference profiles its engine up to 6100 frames (builder.py:58-64): long-batch kernels (LDS-tiled GEMMs, grouped
     tiled expert FFN, row-parallel top-1) and 32-bit index arithmetic at S = 3 x 1524 rows, ragged lengths."""

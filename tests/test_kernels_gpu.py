@@ -192,24 +192,27 @@ def test_linear_layernorm_prologue(eps):
     close(ops.layer_norm(dev(a), dev(g), dev(be), eps), F.layer_norm(a, (K,), g, be, eps), 1e-5, 1e-5)
 
 
-@pytest.mark.parametrize("mean,std", [(0.0, 1.0), (1.5, 3.0), (10.0, 1.0)])
+@pytest.mark.parametrize("mean,std", [(0.0, 1.0), (1.5, 3.0), (10.0, 1.0), (100.0, 1.0), (-40.0, 0.25)])
 def test_linear_folded_layernorm(mean, std):
     """Output-side LayerNorm (engine path): Linear(LN(x)) with the affine folded into the weight at pack time.
-    The one-pass variance loses ~ (mean/std)^2 * 2^-24 relative accuracy, hence the looser bound at mean/std = 10."""
+    Rows with a large common offset (|mean| = 100..160 std) are the adversarial case for a one-pass variance: the kernels
+    take their statistics and their products on rows shifted by a per-row pivot (the row's first element), so the bound
+    does not grow with the offset."""
     from m3asr.plan import fold_layernorm
     M, N, K, T = 100, 1024, 512, 50
     a = rnd(M, K, seed=1) * std + mean
     w, b = rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     g, be = rnd(K, seed=4) * 0.2 + 1.0, rnd(K, seed=5, scale=0.1)
     f = fold_layernorm(w, b, g, be)
-    tol = 3e-5 if mean <= 2 else 4e-4
-    want = F.linear(F.layer_norm(a, (K,), g, be, 1e-12), w, b)
+    tol = 3e-5 if abs(mean) <= 2 else 1e-4
+    want = F.linear(F.layer_norm(a.double(), (K,), g.double(), be.double(), 1e-12), w.double(), b.double()).float()
     got = ops.linear(dev(a), dev(f["ln.weight"]), dev(f["ln.bias"]), ln_folded=(dev(f["ln.wsum"]), None, 1e-12))
+    print("folded LN mean=%g std=%g: max err %.3e" % (mean, std, float((got.cpu() - want).abs().max())))
     close(got, want, tol, tol)
     # conv-module use: LayerNorm -> masked_fill(0) on padded frames -> pointwise conv -> GLU
     lens = torch.tensor([50, 31], dtype=torch.int32)
     pad = (torch.arange(T).view(1, T) >= lens.view(2, 1)).reshape(M, 1)
-    want = F.glu(F.linear(F.layer_norm(a, (K,), g, be, 1e-12).masked_fill(pad, 0.0), w, b), -1)
+    want = F.glu(F.linear(F.layer_norm(a.double(), (K,), g.double(), be.double(), 1e-12).masked_fill(pad, 0.0), w.double(), b.double()), -1).float()
     got = ops.linear(dev(a), dev(f["ln.weight"]), dev(f["ln.bias"]), act=_lib.ACT_GLU, lens=dev(lens), rows_per_batch=T,
                      mask_in=True, ln_folded=(dev(f["ln.wsum"]), dev(f["ln.wbeta"]), 1e-12))
     close(got, want, tol, tol)
