@@ -55,8 +55,8 @@ int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, 
   else if (wmode) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
   else rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
   if (rc) return rc;
-  const float* rows = wmode ? expert_ffn_bf16_rows(w.slab, S, E, D, F) : expert_ffn_f32_rows(w.slab, S, E, D, F);
-  const int n_slices = wmode ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F);
+  const float* rows = wmode ? expert_ffn_w16_rows(wmode, w.slab, S, E, D, F) : expert_ffn_f32_rows(w.slab, S, E, D, F);
+  const int n_slices = wmode ? expert_ffn_w16_slices(wmode, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F);
   return launch_moe_combine(rows, n_slices, w.mapping, gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps,
                             y, S, D, stream);
 }

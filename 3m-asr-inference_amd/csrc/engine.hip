@@ -53,7 +53,14 @@ struct SubW { const float* c1w; const float* c1b; const float* c2w; const float*
 struct Stage {
   std::string name;
   std::function<int(hipStream_t)> run;
+  m3_stage_info info;   // kernel label + algorithmic bytes / FLOPs of the stage (m3_engine_stage_info)
 };
+
+m3_stage_info stage_info(const char* kernel, int launches, double bytes, double flops, bool per_row = true) {
+  m3_stage_info i;
+  i.kernel = kernel; i.launches = launches; i.per_row = per_row ? 1 : 0; i.alg_bytes = bytes; i.flops = flops;
+  return i;
+}
 
 struct Buf { void* ptr; size_t bytes; };
 
@@ -302,9 +309,26 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-static void add_stage(m3_engine* e, const std::string& name, int kernels, std::function<int(hipStream_t)> fn) {
-  e->cur.stages.push_back(Stage{name, std::move(fn)});
+static void add_stage(m3_engine* e, const std::string& name, int kernels, std::function<int(hipStream_t)> fn,
+                      m3_stage_info info = stage_info("", 0, 0.0, 0.0)) {
+  info.launches = kernels;
+  e->cur.stages.push_back(Stage{name, std::move(fn), info});
   e->cur.n_kernels += kernels;
+}
+
+// algorithmic traffic of one GEMM: weights once, A rows once, result once (+ the residual it adds, + side outputs)
+static m3_stage_info gemm_info(const GemmParams& p, bool splitk) {
+  const bool glu = p.act == ACT_GLU;
+  const double M = p.M, N = p.N, K = p.K, Nout = glu ? N / 2 : N;
+  const double wsz = p.w_bf16 ? 2 : 4, asz = p.a_bf16 ? 2 : 4, ysz = p.y_bf16 ? 2 : 4;
+  double a_bytes = M * K * asz;
+  if (p.mode == GEMM_A_CONV3X3S2)   // implicit conv: the input tensor is read once, not 9 times
+    a_bytes = (double)(p.M / (p.conv_T2 * p.conv_F2)) * p.conv_T1 * p.conv_F1 * p.conv_C * asz;
+  double bytes = N * K * wsz + a_bytes + M * Nout * ysz;
+  if (p.resid) bytes += M * Nout * 4;
+  if (p.Yb) bytes += M * Nout * 2;
+  if (p.ln_out) bytes += M * (K - p.K1) * 4;
+  return stage_info(gemm_kernel_label(p, splitk), 1, bytes, 2.0 * M * N * K, p.mode != GEMM_A_CONV3X3S2);
 }
 
 // fp32_weights: the router GEMMs keep fp32 weights in every mode (a flipped top-1 is a discrete error)
@@ -313,10 +337,10 @@ static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool f
   size_t need = 0;
   if (gemm_f32_splitk_plan(p, &need) >= 2 && e->cur.splitk_ws != nullptr && need <= e->cur.splitk_bytes) {
     float* ws = e->cur.splitk_ws; const size_t wsb = e->cur.splitk_bytes;
-    add_stage(e, name, 2, [p, ws, wsb](hipStream_t s) { return launch_gemm_f32_splitk(p, ws, wsb, s); });
+    add_stage(e, name, 2, [p, ws, wsb](hipStream_t s) { return launch_gemm_f32_splitk(p, ws, wsb, s); }, gemm_info(p, true));
     return;
   }
-  add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); });
+  add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); }, gemm_info(p, false));
 }
 
 static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w, int D, const Plan& pl, float* xout) {
@@ -328,7 +352,8 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   const int idim = c.input_dim;
   const float* cm = e->cmvn_mean; const float* ci = e->cmvn_istd;
   const bool a16 = e->cur.a16;    // c1, c2 only feed GEMMs: kept as bf16; the Linear also writes the bf16 copy of x
-  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s, 1, a16); });
+  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s, 1, a16); },
+            stage_info("conv1_relu_kernel", 1, (double)B * T * idim * 4 + (double)B * T1 * F1 * D * (a16 ? 2 : 4), 18.0 * B * T1 * F1 * D, false));
   GemmParams g;
   g.a_bf16 = a16; g.y_bf16 = a16;
   g.mode = GEMM_A_CONV3X3S2; g.A = c1; g.lda = 4;
@@ -352,7 +377,7 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
     add_stage(e, pfx + "pack", a16 ? 2 : 1, [=](hipStream_t s) {
       if (int rc = launch_local_gather(xpad, pad_of, S, D * 4, xout, s)) return rc;
       return a16 ? launch_local_gather(xbpad, pad_of, S, D * 2, xb, s) : 0;
-    });
+    }, stage_info("row_permute_kernel", 1, (double)S * D * (a16 ? 12 : 8) + 4.0 * S, 0.0));
   }
 }
 
@@ -412,7 +437,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float scale = 1.f / sqrtf((float)dk);
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
       return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0);
-    });
+    }, stage_info("relpos_attention_kernel", 1, (double)S * D * (12 + (a16 ? 2 : 4)) + (double)Tp * D * 4, 6.0 * Tp * D * S));
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
     o.resid = x; o.ldr = D;
@@ -433,7 +458,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* ng = cnn_ln ? w.n_cnn.g : nullptr; const float* nb = cnn_ln ? w.n_cnn.b : nullptr;
     add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
       return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16, pad_of, row0, lens);
-    });
+    }, stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * (4 + (a16 ? 2 : 4)) + (double)K * D * 4, 2.0 * K * D * S));
     GemmParams h;
     h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
     h.row_len = live_len; h.rows_per_batch = live_rpb; h.mask_out = 1; h.resid = x; h.ldr = D;
@@ -453,7 +478,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     add_gemm(e, pfx + "ffn.w2", h);
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     void* xbo = a16 ? xb : nullptr;
-    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo); });
+    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo); },
+              stage_info("layernorm_kernel", 1, (double)S * D * (a16 ? 10 : 8), 8.0 * S * D));
   } else {  // x = LN_final(x + 0.5 * gate * Expert_g(LN(x)))     (positionwise_feed_forward.py:209-265)
     const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
     const int Etot = c.num_experts * world, E = c.num_experts, De = c.embed_dim;
@@ -480,10 +506,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       add_gemm(e, pfx + "moe_router", r, true);
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
         return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
-      });
+      }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (E + 1), 0.0));
       add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
         return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
-      });
+      }, stage_info("expert_ffn_f32_kernel", 1, -1.0, 4.0 * D * F * S));
     } else if (fused_route) {
       // router (x half, norm_ff folded; embed half precomputed for all layers by "router_e_all") + SoftmaxTopK +
       // ScatterMapping in ONE launch; the expert kernel applies norm_ff itself while it gathers rows
@@ -493,10 +519,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       add_stage(e, pfx + "moe_route", 1, [=](hipStream_t s) {
         return launch_moe_route(x, D, D, wx, wsum, rb, eall, ld_e, eps, lens, Tp, S, E, gidx, gval, mw.mapping, mw.acc,
                                 mw.pos, s);
-      });
+      }, stage_info("moe_route_kernel", 1, (double)E * D * 4 + (double)S * (D + E) * 4 + 16.0 * S, 2.0 * S * E * D));
       add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
         return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
-      });
+      }, stage_info("expert_ffn_f32_kernel", 1, -1.0, 4.0 * D * F * S));
     } else {
     GemmParams r;
     r.mode = GEMM_A_CONCAT2; r.A = pl.emb; r.lda = De; r.K1 = De; r.A2 = x; r.lda2 = D;
@@ -511,31 +537,35 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
         return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
-      });
+      }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (E + 1), 0.0));
     } else {
       add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
         return launch_softmax_top1(rl, Etot, live_len, live_rpb, S, Etot, gidx, gval, s);
-      });
+      }, stage_info("softmax_top1_kernel", 1, (double)S * (Etot * 4 + 8), 0.0));
       add_stage(e, pfx + "moe_local.index", 1, [=](hipStream_t s) {
         return launch_moe_index(gidx, S, E, mw.mapping, mw.acc, mw.pos, s);
-      });
+      }, stage_info("moe_index_kernel", 1, 12.0 * S + 4.0 * (E + 1), 0.0));
     }
     const bool e16 = c.weight_dtype != M3_F32, e8 = c.weight_dtype == M3_FP8;
     const float *es1 = w.es1, *es2 = w.es2;
-    const bool etiled = e16 ? expert_ffn_bf16_tiled(S, E, D, F) : expert_ffn_f32_tiled(S, E, D, F);
-    add_stage(e, pfx + "moe_local.expert", etiled ? 2 : 1, [=](hipStream_t s) {
+    const int wmode = e8 ? 2 : (e16 ? 1 : 0);
+    const int elaunches = e16 ? expert_ffn_w16_launches(wmode, S, E, D, F) : (expert_ffn_f32_tiled(S, E, D, F) ? 2 : 1);
+    add_stage(e, pfx + "moe_local.expert", elaunches, [=](hipStream_t s) {
       if (e8) return launch_expert_ffn_w8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, mw.slab, s);
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
-    });
+    }, stage_info(e16 ? expert_ffn_w16_kernel(wmode, S, E, D, F)
+                      : (expert_ffn_f32_tiled(S, E, D, F) ? "expert_gemm_f32_tiled_kernel" : "expert_ffn_f32_kernel"),
+                  1, -1.0, 4.0 * D * F * S));
     }
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
     const bool e16c = c.weight_dtype != M3_F32;
-    const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_bf16_rows(mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
-    const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_bf16_slices(S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
+    const int wmode_c = c.weight_dtype == M3_FP8 ? 2 : 1;
+    const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_w16_rows(wmode_c, mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
+    const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_w16_slices(wmode_c, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
-    });
+    }, stage_info("moe_combine_kernel", 1, (double)S * D * 4 * (eslices + 2) + (a16 ? 2.0 * S * D : 0.0), (double)S * D * (eslices + 10)));
     const std::string b = pfx.substr(0, pfx.size() - 1);
     e->cur.buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
     e->cur.buffers[b + ".gate_value"] = Buf{gval, (size_t)S * 4};
@@ -659,6 +689,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_expert_ffn_w8_kernels()) return rc;
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
+  if (int rc = init_expert_ffn_fused_bf16_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
@@ -710,10 +741,12 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
   {
     int32_t* lens = pl.lens;
-    add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); });
+    add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); },
+              stage_info("subsample_lens_kernel", 1, 8.0 * B, 0.0, false));
     if (e->cur.packed) {   // row plan of the packed layout: first row of every utterance, packed -> padded row map
       int32_t* row0 = pl.row0; int32_t* pad_of = pl.pad_of;
-      add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s); });
+      add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s); },
+                stage_info("pack_plan_kernel", 1, 8.0 * B + 4.0 * B * Tp, 0.0, false));
     }
   }
   // ---- p = linear_pos(pe[:T']) for all blocks at once (attention.py:345; input-independent, so with
@@ -748,7 +781,8 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   {
     float* x = pl.x; float* emb = pl.emb;
     const float* g = e->e_after.g; const float* b = e->e_after.b;
-    add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); });
+    add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); },
+              stage_info("layernorm_kernel", 1, 8.0 * S * De, 8.0 * S * De));
   }
   // embed half of every layer's router product in one GEMM: emb does not change across the main blocks
   if ((c.fuse_route == 2 && c.ep_world_size <= 1 && S < 1024) ||
@@ -780,11 +814,13 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     const float* ob = e->output_bias;
     const int V = c.output_dim;
     if (c.log_softmax_out) {
-      add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(lout, ob, lout, (size_t)S, V, s); });
+      add_stage(e, "log_softmax", 1, [=](hipStream_t s) { return launch_log_softmax_bias(lout, ob, lout, (size_t)S, V, s); },
+                stage_info("log_softmax_bias_kernel", 1, 8.0 * S * V, 4.0 * S * V));
     }   // without log-softmax a prior is folded into out_linear's bias when the plan is packed (plan.py)
     if (e->cur.packed) {
       const int32_t* row0 = pl.row0;
-      add_stage(e, "unpack", 1, [=](hipStream_t s) { return launch_unpack_rows(lout, row0, B, Tp, V, logits, s); });
+      add_stage(e, "unpack", 1, [=](hipStream_t s) { return launch_unpack_rows(lout, row0, B, Tp, V, logits, s); },
+                stage_info("unpack_rows_kernel", 1, 8.0 * S * V, 0.0, false));
     }
   }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
@@ -804,6 +840,12 @@ const char* m3_engine_stage_name(const m3_engine* engine, int index) {
   return engine->cur.stages[index].name.c_str();
 }
 int m3_engine_num_captures(const m3_engine* engine) { return engine ? engine->n_captures : 0; }
+int m3_engine_stage_info(const m3_engine* engine, int index, m3_stage_info* info) {
+  M3_REQUIRE(engine && info, "engine_stage_info: null argument");
+  M3_REQUIRE(index >= 0 && index < (int)engine->cur.stages.size(), "engine_stage_info: no stage %d", index);
+  *info = engine->cur.stages[index].info;
+  return 0;
+}
 int m3_engine_num_kernels(const m3_engine* engine) { return engine ? engine->cur.n_kernels : 0; }
 
 int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream stream) {

@@ -372,6 +372,20 @@ static int f32_tiled_min_rows() {   // below this many rows the K-split kernel f
   return v;
 }
 
+// long batches: LDS-tiled kernel (everything but the affine-LayerNorm / concat router GEMM, whose output is 32 wide)
+// (needs enough 64 x 64 tiles to occupy the chip: below ~160 the K-split kernel's many small workgroups win)
+static bool gemm_f32_uses_tiled(const GemmParams& p) {
+  const bool glu = p.act == ACT_GLU;
+  return p.M >= f32_tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_f32_tiled_supports(p);
+}
+
+// which kernel launch_gemm_f32 / the engine's split-K front end will run for this problem (sizes / mode only)
+const char* gemm_kernel_label(const GemmParams& p, bool splitk) {
+  if (splitk) return "gemm_f32_splitk_kernel";
+  if (p.w_bf16) return gemm_bf16w_uses_tiled(p) ? "gemm_bf16w_tiled_kernel" : "gemm_bf16w_kernel";
+  return gemm_f32_uses_tiled(p) ? "gemm_f32_tiled_kernel" : "gemm_f32_kernel";
+}
+
 int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   if (pin.w_bf16) return launch_gemm_bf16w(pin, stream);
   GemmParams p = pin;
@@ -396,10 +410,7 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
   M3_REQUIRE(p.ln_out == nullptr || ln == LN_PRO, "gemm: ln_out needs the affine LayerNorm prologue");
   M3_REQUIRE(!(ln == LN_EPI && p.mask_in) || p.ln_wbeta, "gemm: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm: mask needs row_len");
-  // long batches: LDS-tiled kernel (everything but the affine-LayerNorm / concat router GEMM, whose output is 32 wide)
-  // (needs enough 64 x 64 tiles to occupy the chip: below ~160 the K-split kernel's many small workgroups win)
-  if (p.M >= f32_tiled_min_rows() && (long)cdiv(p.M, 64) * cdiv(glu ? p.N / 2 : p.N, 64) >= 160 && gemm_f32_tiled_supports(p))
-    return launch_gemm_f32_tiled(p, stream);
+  if (gemm_f32_uses_tiled(p)) return launch_gemm_f32_tiled(p, stream);
   const int Nout = glu ? p.N / 2 : p.N;
   // row tile: 16*MT rows per workgroup; short inputs are cut into 16-row tiles to fill the chip, but more
   // workgroups than fit at once (2 per CU) only serialise: then prefer fatter tiles

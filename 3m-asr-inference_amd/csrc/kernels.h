@@ -49,6 +49,7 @@ struct GemmParams {
 };
 int launch_gemm_f32(const GemmParams& p, hipStream_t stream);   // dispatches to launch_gemm_bf16w when p.w_bf16
 int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
+const char* gemm_kernel_label(const GemmParams& p, bool splitk);   // the kernel these dispatchers will run (observability)
 bool gemm_bf16w_uses_tiled(const GemmParams& p);   // the choice launch_gemm_bf16w makes for this problem (sizes / mode only)
 // deep-K, few-tile fp32 problems (conv2 / subsampling Linear at short inputs): split-K tiled kernel + reduce (gemm_f32_splitk.hip)
 int gemm_f32_splitk_plan(const GemmParams& p, size_t* ws_bytes);   // number of K ranges (0 = not applicable) and workspace
@@ -102,6 +103,19 @@ int launch_expert_ffn_w8(const float* x, int ldx, const int32_t* pos, const int3
 bool expert_ffn_bf16_tiled(int S, int E, int D, int F);
 float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F);
 int expert_ffn_bf16_slices(int S, int E, int D, int F);
+// what the 16-bit / fp8 dispatchers above run for a shape (wmode 1 = bf16 weights, 2 = fp8 weights), for the combine
+// step and for launch accounting: where the result rows are, in how many partial slabs, how many kernel launches
+float* expert_ffn_w16_rows(int wmode, float* slab, int S, int E, int D, int F);
+int expert_ffn_w16_slices(int wmode, int S, int E, int D, int F);
+int expert_ffn_w16_launches(int wmode, int S, int E, int D, int F);
+const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F);
+// bf16, long batches (D = 512): ONE kernel, H stays in registers (moe_expert_fused_bf16.hip); ybuf: fsplit x S x D fp32
+bool expert_ffn_fused_bf16_applies(int S, int E, int D, int F);
+int expert_ffn_fused_bf16_fsplit(int S, int E, int D, int F);
+int init_expert_ffn_fused_bf16_kernels();
+int launch_expert_ffn_fused_bf16(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
+                                 int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* ybuf,
+                                 hipStream_t stream);
 // long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
 int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                                   int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced,

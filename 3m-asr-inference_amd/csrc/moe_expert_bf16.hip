@@ -171,6 +171,27 @@ float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F) {   // what
 }
 int expert_ffn_bf16_slices(int S, int E, int D, int F) { return expert_ffn_bf16_tiled(S, E, D, F) ? 1 : F / kExpertSlice; }
 
+// bf16 weights take the fused one-kernel form where it applies (its result: fsplit slabs of sorted rows at the start of the
+// slab region); fp8 weights and everything else keep the layouts above
+static bool w16_fused(int wmode, int S, int E, int D, int F) {
+  return wmode == 1 && expert_ffn_fused_bf16_applies(S, E, D, F) &&
+         (size_t)expert_ffn_fused_bf16_fsplit(S, E, D, F) * S * D * 4 <= expert_ffn_slab_bytes(S, D, F);
+}
+float* expert_ffn_w16_rows(int wmode, float* slab, int S, int E, int D, int F) {
+  return w16_fused(wmode, S, E, D, F) ? slab : expert_ffn_bf16_rows(slab, S, E, D, F);
+}
+int expert_ffn_w16_slices(int wmode, int S, int E, int D, int F) {
+  return w16_fused(wmode, S, E, D, F) ? expert_ffn_fused_bf16_fsplit(S, E, D, F) : expert_ffn_bf16_slices(S, E, D, F);
+}
+int expert_ffn_w16_launches(int wmode, int S, int E, int D, int F) {
+  return w16_fused(wmode, S, E, D, F) ? 1 : (expert_ffn_bf16_tiled(S, E, D, F) ? 2 : 1);
+}
+const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F) {
+  if (w16_fused(wmode, S, E, D, F)) return "expert_ffn_fused_bf16_kernel";
+  if (expert_ffn_bf16_tiled(S, E, D, F)) return wmode == 2 ? "gemm_bf16w_tiled_kernel<grouped,fp8>" : "gemm_bf16w_tiled_kernel<grouped>";
+  return wmode == 2 ? "expert_ffn_w8_kernel" : "expert_ffn_bf16w_kernel";
+}
+
 int init_expert_ffn_bf16_kernels() {
   static bool done = false;
   if (done) return 0;
@@ -186,6 +207,8 @@ int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const i
   M3_REQUIRE((D & 31) == 0 && D <= 2048, "expert_ffn_bf16w: idim=%d must be a multiple of 32 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_bf16w: ldx=%d must be a multiple of 4", ldx);
+  if (w16_fused(1, S, E, D, F))
+    return launch_expert_ffn_fused_bf16(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab, stream);
   if (expert_ffn_bf16_tiled(S, E, D, F))
     return launch_expert_ffn_bf16w_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
                                          expert_ffn_bf16_rows(slab, S, E, D, F), stream);

@@ -61,6 +61,11 @@ _P = C.POINTER
 
 # name -> (restype, argtypes).  Must list every symbol include/m3asr.h declares
 # (tests/test_abi.py checks this table against the header and the .so).
+class StageInfo(C.Structure):        # m3_stage_info
+    _fields_ = [("kernel", C.c_char_p), ("launches", C.c_int32), ("per_row", C.c_int32),
+                ("alg_bytes", C.c_double), ("flops", C.c_double)]
+
+
 SIGNATURES = {
     "m3_abi_version": (_i, []),
     "m3_last_error": (_cp, []),
@@ -134,6 +139,7 @@ SIGNATURES = {
     "m3_engine_run": (_i, [_vp, _i, _i, _vp]),
     "m3_engine_buffer": (_i, [_vp, _cp, _P(_vp), _P(_sz)]),
     "m3_engine_num_kernels": (_i, [_vp]),
+    "m3_engine_stage_info": (_i, [_vp, _i, _vp]),
 }
 
 _lib = None

@@ -39,6 +39,10 @@ class EncoderConfig:
     weight_dtype: str = "f32"
     log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
 
+    def fp8_label(self):
+        """What the fp8 mode of this config computes in (for reports: a weight-only mode must not read as fp8 MFMA)."""
+        return "fp8 e4m3 weight-only (W8A16: dequantised to bf16 at the MFMA input, bf16 MFMA)"
+
     @property
     def d_k(self):
         return self.attention_dim // self.attention_heads

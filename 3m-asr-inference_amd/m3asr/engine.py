@@ -182,6 +182,17 @@ class Engine:
     def num_kernels(self):
         return self.lib.m3_engine_num_kernels(self.handle)
 
+    def stage_info(self):
+        """Per stage of the bound shape: dict(name, kernel, launches, per_row, alg_bytes, flops) -- what the stage launches
+        and its algorithmic HBM bytes / FLOPs (alg_bytes < 0: data-dependent, the grouped expert FFN)."""
+        out = []
+        for i, name in enumerate(self.stage_names()):
+            si = _lib.StageInfo()
+            check(self.lib.m3_engine_stage_info(self.handle, i, C.byref(si)), "m3_engine_stage_info")
+            out.append(dict(name=name, kernel=(si.kernel or b"").decode(), launches=si.launches, per_row=bool(si.per_row),
+                            alg_bytes=si.alg_bytes, flops=si.flops))
+        return out
+
     def run_stages(self, first, last, stream=None):
         st = stream if stream is not None else self.stream
         check(self.lib.m3_engine_run(self.handle, first, last, C.c_void_p(st.cuda_stream)), "m3_engine_run")

@@ -10,10 +10,14 @@ data-path collective, weak scaling.
 
 A step = one encoder forward (feat, feat_len resident in HBM -> logits in HBM), replayed as a hipGraph.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     : the dominant kernel (grouped expert FFN) -- algorithmic bytes per launch / measured
-                 HIP-event duration on the engine's stream vs the 8 TB/s HBM peak;
-  cpu_baseline : the oracle's plain-torch fp32 forward of the same workload timed on the host cores
-                 (kind "port": the reference's CUDA/TensorRT path cannot be built here).
+  roofline        : the kernel family that holds the largest share of the forward's GPU time (picked from the in-run
+                    per-stage HIP-event timings, m3_engine_stage_info gives each stage's kernel and algorithmic bytes /
+                    FLOPs) -- algorithmic bytes (or FLOPs) / measured duration vs the 8 TB/s HBM (or MFMA) peak;
+  roofline_expert : the same for the north-star kernel, the grouped expert FFN, timed in situ;
+  forward         : whole-forward fractions -- algorithmic bytes / one-stream latency / HBM peak, FLOPs / MFMA peak --
+                    and the p50 / p99 latency of >= 50 hipEvent-timed forwards;
+  cpu_baseline    : the oracle's plain-torch fp32 forward of the same workload timed on the host cores
+                    (kind "port": the reference's CUDA/TensorRT path cannot be built here).
 """
 import argparse
 import json
@@ -42,6 +46,8 @@ else:
 
 import numpy as np
 import torch
+
+T_START = time.perf_counter()
 
 
 def parse():
@@ -78,6 +84,10 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 runs (nccl = RCCL; gloo: rehearsal of the multi-rank path "
                          "on a box with fewer GPUs than ranks -- ranks then share devices)")
+    ap.add_argument("--pmc-safe", action="store_true",
+                    help="for `rocprofv3 --pmc ... -- python3 bench.py --pmc-safe`: one execution context and 4 host threads "
+                         "(the counter-collection abort of round 1 followed the host thread count, DESIGN.md 6)")
+    ap.add_argument("--latency-iters", type=int, default=100, help="hipEvent-timed single forwards for p50 / p99 (>= 50)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
     return ap.parse_args()
@@ -124,7 +134,9 @@ def balance_router(eng, cpu_weights):
             valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
             mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
         w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
-        w -= torch.outer(w @ mu, mu) / (mu @ mu)
+        # (element-wise ops + reductions only: no GEMM / GEMV call, so the process never loads rocBLAS / Tensile code
+        # objects -- see DESIGN.md 6, "the --pmc abort")
+        w -= ((w * mu).sum(1, keepdim=True) * mu) / (mu * mu).sum()
         eng.run_stages(idx, idx + 1)                                              # logits with the new weights
         first = idx + 1
         cpu_weights["blocks.%d.feed_forward.router_weights" % li] = w.t().contiguous().cpu()
@@ -134,16 +146,38 @@ def balance_router(eng, cpu_weights):
 
 def main():
     args = parse()
+    if args.pmc_safe or _profiler_attached():
+        # rocprofv3 --pmc aborts (SIGSEGV in the tool's counter-collection thread) when a hipGraph is captured /
+        # instantiated in the profiled process -- the process survives plan packing, calibration and eager forwards and dies
+        # at the first m3_engine_forward(use_graph=1): profile eager launches on one context
+        args.streams = 1
+        args.no_graph = True
+        args.latency_iters = 50
+        args.pmc_safe = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if args.dist_backend == "gloo":          # rehearsal: more ranks than devices is fine, they share
         local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:      # host-side weight generation / packing: do not oversubscribe the cores with N ranks x all threads
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    prof = _profiler_attached()
+
+    def phase(msg):
+        if prof:
+            print("bench[%.1fs]: %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+    from m3asr.config import EncoderConfig, subsampled_len
+    from m3asr.weights import make_weights
+
+    # host-side work first (weights are generated on the CPU), the device is touched afterwards
+    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts, weight_dtype=args.weight_dtype)
+    weights = make_weights(cfg, seed=0)
+    phase("weights generated on the host")
+    torch.cuda.set_device(local_rank)
+    phase("device selected")
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
@@ -151,12 +185,7 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    from m3asr.config import EncoderConfig, subsampled_len
-    from m3asr.weights import make_weights
     from m3asr.engine import Engine
-
-    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts, weight_dtype=args.weight_dtype)
-    weights = make_weights(cfg, seed=0)
 
     # synthetic input: U[0,1) features as data/generate_trtexec_inputs.py:7 of the reference; each rank its own utterance
     rng = np.random.default_rng(1234 + rank)
@@ -175,9 +204,11 @@ def main():
     packed = {"auto": None, "on": True, "off": False}[args.packed_rows]
     # the staged-route engine exposes xn / the router stage, which the synthetic-router calibration needs
     eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False, packed_rows=packed)
+    phase("engine built (plan packed, weights on the device)")
     if args.routing == "balanced":
         eng.bind(feat, feat_len)
         balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
+        phase("synthetic routers calibrated")
     route = {"staged": 0, "fused": 1, "split": 2}[args.route_mode] if args.route_mode else (1 if args.fuse_route else 0)
     if route:                                # rebuild from the calibrated state_dict
         del eng
@@ -188,6 +219,7 @@ def main():
     eng.bind(feat, feat_len)
     eng.forward(use_graph=False)
     eng.stream.synchronize()
+    phase("first forward done")
     use_graph = not args.no_graph
     # extra execution contexts: same weights, own utterance / stream / workspace / graph
     ctxs = [eng]
@@ -203,9 +235,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase("contexts ready")
     for i in range(args.warmup * len(ctxs)):
         ctxs[i % len(ctxs)].forward(use_graph=use_graph)
+    phase("warm-up enqueued")
     barrier()
+    phase("warm-up done (device synchronised)")
     t0 = time.perf_counter()
     for i in range(args.steps):
         ctxs[i % len(ctxs)].forward(use_graph=use_graph)
@@ -218,41 +253,95 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    # latency of one forward when it has the GPU to itself (one context)
+    phase("timed region done")
+    # latency of one forward when it has the GPU to itself (one context): back-to-back mean, and the distribution of
+    # individually hipEvent-timed forwards (events recorded on the engine's own stream, one forward in flight at a time)
     t1 = time.perf_counter()
-    for _ in range(50):
+    n_lat = 5 if args.pmc_safe else 50
+    for _ in range(n_lat):
         eng.forward(use_graph=use_graph)
+        if args.pmc_safe:          # counter collection: keep the dispatches in flight bounded
+            eng.stream.synchronize()
     eng.stream.synchronize()
-    latency_ms = (time.perf_counter() - t1) / 50 * 1e3
+    latency_ms = (time.perf_counter() - t1) / n_lat * 1e3
+    phase("back-to-back forwards done")
+    lat = []
+    for _ in range(max(50, args.latency_iters)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+        eng.forward(use_graph=use_graph)
+        e1.record(eng.stream)
+        e1.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    lat = np.sort(np.array(lat))
+    phase("hipEvent-timed forwards done")
     frames_per_step = world * n_frames
     value = frames_per_step / (dt / args.steps)
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the engine's stream ----
-    roofline = None
+    # ---- rooflines, measured live with HIP events on the engine's stream ----
+    roofline = roofline_expert = forward = None
     if rank == 0:
-        names, ms = stage_times(eng)
-        if args.profile_stages:
-            for n_, m_ in zip(names, ms):
-                if not (n_.startswith("blocks.") or n_.startswith("embed.blocks.")) or ".0." in n_ or ".9." in n_:
-                    print("%-40s %8.2f us" % (n_, m_ * 1e3), file=sys.stderr)
-            print("sum of stages %.3f ms, %d kernels" % (ms.sum(), eng.num_kernels()), file=sys.stderr)
-        idx = [i for i, n_ in enumerate(names) if n_.endswith("moe_local.expert")]
         D, F, E, S = cfg.attention_dim, cfg.hidden_units, cfg.num_experts, B * subsampled_len(T)
-        # algorithmic bytes per launch: touched experts x (2DF + F + D) x 4 B  +  S x (D in + D out) x 4 B.
-        # acc_histogram of the last layer is live in the workspace; touched counts differ per layer by +-2, so
-        # use the per-layer routing recorded in gate_idx.
+        info = eng.stage_info()
+        names, ms = stage_times(eng)
+        live = S                                   # rows the blocks really work on (packed ragged batch: the valid frames)
+        if B > 1 and eng.packed_rows():
+            live = int(eng.buffer("row0", torch.int32)[B])
+        # experts each layer touched (from the routing taps of the timed workload) -> algorithmic bytes of its launch
+        # (SURVEY 8d): touched x (2DF weights + biases [+ scales]) + live rows x (D in + D out) x 4 B
         touched = []
         for li in range(cfg.num_blocks):
             g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
             touched.append(len(np.unique(g[g >= 0])))
         wsz = {"f32": 4, "bf16": 2, "fp8": 1}[cfg.weight_dtype]   # expert weights in weight_dtype, biases / scales / rows fp32
-        extra = (F + D) * 4 * (2 if cfg.weight_dtype == "fp8" else 1)   # biases (+ per-row scales)
-        bytes_alg = np.array([t_ * (2 * D * F * wsz + extra) + S * 2 * D * 4 for t_ in touched], dtype=np.float64)
-        # duration of the roofline kernel IN SITU: whole forwards are enqueued stage by stage on the engine stream
-        # (the GPU stays the bottleneck: ~3.5 us host cost per launch vs ~8 us per kernel) with HIP events only around
-        # each layer's expert launch, so the kernel sees the cache state of a real forward -- repeated in isolation its
-        # ~100 MB of weights would sit in the 256 MB Infinity Cache and read 25 % faster
-        st = eng.stream
+        extra = (F + D) * 4 * (2 if cfg.weight_dtype == "fp8" else 1)
+        exp_bytes = [t_ * (2 * D * F * wsz + extra) + live * 2 * D * 4 for t_ in touched]
+        peak_bw = 8000.0                                                        # GB/s (MI355X_MICROARCH.md)
+        peak_tf = {"f32": 157.3, "bf16": 2500.0, "fp8": 2500.0}[cfg.weight_dtype]   # dense MFMA TFLOP/s of the arithmetic
+        fam, li = {}, 0
+        tot_bytes = tot_flops = 0.0
+        for st, t_ms in zip(info, ms):
+            scale = (live / float(S)) if st["per_row"] else 1.0
+            if st["alg_bytes"] < 0:                # the grouped expert FFN of layer li
+                by, fl = exp_bytes[li], st["flops"] * scale
+                li += 1
+            else:
+                by, fl = st["alg_bytes"] * scale, st["flops"] * scale
+            f_ = fam.setdefault(st["kernel"], [0.0, 0.0, 0.0, 0])
+            f_[0] += t_ms; f_[1] += by; f_[2] += fl; f_[3] += st["launches"]
+            tot_bytes += by; tot_flops += fl
+        t_all = float(sum(v[0] for v in fam.values()))
+
+        def roof(t_ms, by, fl, launches, kernel):
+            """bound = whichever roofline leaves less headroom for this kernel at this shape"""
+            t_s = t_ms * 1e-3
+            f_hbm, f_mfma = by / t_s / (peak_bw * 1e9), fl / t_s / (peak_tf * 1e12)
+            d = {"kernel": kernel, "time_share": round(t_ms / t_all, 4), "launches_per_forward": launches,
+                 "avg_launch_us": round(t_ms * 1e3 / max(launches, 1), 2),
+                 "alg_bytes_per_launch": int(by / max(launches, 1)), "flops_per_launch": int(fl / max(launches, 1))}
+            if f_hbm >= f_mfma:
+                d.update(bound="hbm", achieved=round(by / t_s / 1e9, 1), peak=peak_bw, unit="GB/s", frac=round(f_hbm, 4))
+            else:
+                d.update(bound="mfma", achieved=round(fl / t_s / 1e12, 2), peak=peak_tf, unit="TFLOP/s", frac=round(f_mfma, 4))
+            return d
+
+        dom = max(fam, key=lambda k: fam[k][0])
+        roofline = roof(fam[dom][0], fam[dom][1], fam[dom][2], fam[dom][3], dom)
+        roofline["families"] = {k: {"time_share": round(v[0] / t_all, 4), "launches": v[3],
+                                    "hbm_frac": round(v[1] / (v[0] * 1e-3) / (peak_bw * 1e9), 4)}
+                                for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}
+        if args.profile_stages:
+            for st, m_ in zip(info, ms):
+                n_ = st["name"]
+                if not (n_.startswith("blocks.") or n_.startswith("embed.blocks.")) or ".0." in n_ or ".9." in n_:
+                    print("%-40s %-34s %8.2f us" % (n_, st["kernel"], m_ * 1e3), file=sys.stderr)
+            print("sum of stages %.3f ms, %d kernels" % (ms.sum(), eng.num_kernels()), file=sys.stderr)
+        # the grouped expert FFN IN SITU: whole forwards are enqueued stage by stage on the engine stream (the GPU stays
+        # the bottleneck: ~3.5 us host cost per launch vs ~8 us per kernel) with HIP events only around each layer's
+        # expert launch, so the kernel sees the cache state of a real forward -- repeated in isolation its ~100 MB of
+        # weights would sit in the 256 MB Infinity Cache and read 25 % faster
+        idx = [i for i, st in enumerate(info) if st["alg_bytes"] < 0]
+        st_ = eng.stream
         acc_t = np.zeros(len(idx))
         passes = 20
         for _ in range(passes):
@@ -260,35 +349,45 @@ def main():
             for i_ in idx:
                 eng.run_stages(cur, i_)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(st)
+                e0.record(st_)
                 eng.run_stages(i_, i_ + 1)
-                e1.record(st)
+                e1.record(st_)
                 evs.append((e0, e1))
                 cur = i_ + 1
             eng.run_stages(cur, len(names))
-            st.synchronize()
-            acc_t += np.array([a.elapsed_time(b) for a, b in evs])
-        dur = acc_t / passes * 1e-3
-        achieved = float((bytes_alg / dur).mean() / 1e9)
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs) of the
-        # SAME kernel at the same shape with HBM-cold weights (tools/pmc_expert.py -> profiles/r01_pmc_expert.json; the
-        # full bench.py segfaults inside the profiler's counter collection on this pool), scaled by the touched-expert
-        # count of this run (the probe's routing touched 25.33 experts per layer)
-        traffic = None
-        kname = {"f32": "expert_ffn_f32_kernel", "bf16": "expert_ffn_bf16w_kernel", "fp8": "expert_ffn_w8_kernel"}[cfg.weight_dtype]
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_expert.json")
-        if os.path.exists(pmc) and B == 1 and T == 206:
+            st_.synchronize()
+            acc_t += np.array([a.elapsed_time(b_) for a, b_ in evs])
+        dur_ms = acc_t / passes
+        n_l = sum(info[i_]["launches"] for i_ in idx)
+        roofline_expert = roof(float(dur_ms.sum()), float(sum(exp_bytes)), float(sum(info[i_]["flops"] for i_ in idx)) * live / S,
+                               n_l, info[idx[0]]["kernel"])
+        roofline_expert.update(experts_touched_mean=round(float(np.mean(touched)), 2), experts_touched=touched,
+                               rows_per_touched_expert=round(live / max(float(np.mean(touched)), 1.0), 1))
+        # HBM bytes per launch from hardware counters: `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over THIS
+        # script (bench.py --pmc-safe, same workload), summarised by tools/pmc_summarize.py into profiles/ (counters cannot
+        # be read from inside the profiled process); traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, the gfx950
+        # correction of MI355X_MICROARCH.md (HBM).  null when no summary of this exact workload is committed.
+        for r_ in (roofline, roofline_expert):
+            r_["traffic"] = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+        if os.path.exists(pmc):
             try:
-                ent = json.load(open(pmc))[cfg.weight_dtype]
-                per = [v for k, v in ent["kernels"].items() if "expert_ffn" in k][0]["traffic_bytes_per_launch"]
-                traffic = int(per * float(np.mean(touched)) / ent["meta"]["experts_touched_mean"])
+                ent = json.load(open(pmc))
+                if ent.get("workload") == [cfg.weight_dtype, B, T, cfg.num_blocks, cfg.num_experts]:
+                    for r_ in (roofline, roofline_expert):
+                        k_ = [v for k, v in ent["kernels"].items() if k.startswith(r_["kernel"].split("<")[0])]
+                        if k_:
+                            r_["traffic"] = int(np.mean([v["traffic_bytes_per_launch"] for v in k_]))
+                            r_["traffic_source"] = "profiles/r02_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe)"
             except Exception:
-                traffic = None
-        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "avg_launch_us": round(float(dur.mean() * 1e6), 2),
-                    "alg_bytes_per_launch": int(bytes_alg.mean()),
-                    "experts_touched_mean": round(float(np.mean(touched)), 2), "experts_touched": touched}
+                pass
+        forward = {"alg_bytes": int(tot_bytes), "flops": int(tot_flops),
+                   "latency_ms": {"p50": round(float(np.median(lat)), 4), "p99": round(float(lat[int(0.99 * (len(lat) - 1))]), 4),
+                                  "min": round(float(lat[0]), 4), "n": int(len(lat)), "timer": "hipEvent pair per forward, engine stream"},
+                   "hbm_frac_one_stream": round(tot_bytes / (float(np.median(lat)) * 1e-3) / (peak_bw * 1e9), 4),
+                   "hbm_frac_at_value": round(tot_bytes * (value / frames_per_step) / (peak_bw * 1e9), 4),
+                   "mfma_frac_at_value": round(tot_flops * (value / frames_per_step) / (peak_tf * 1e12), 4),
+                   "mfma_peak_tflops": peak_tf, "live_rows": live, "padded_rows": S}
 
     # ---- CPU baseline: the oracle (plain-torch fp32 restatement) on the host cores, rank 0, N=1 only ----
     cpu = None
@@ -330,28 +429,46 @@ def main():
 
     if rank == 0:
         metric = "encoder frames/sec, 18Lx32e Conformer-MoE, 206-frame utterance"
-        if args.varlen or B != 1 or T != 206:
+        if args.varlen or B != 1 or T != 206 or cfg.num_blocks != 18 or cfg.num_experts != 32:
             metric = "encoder frames/sec, %dLx%de Conformer-MoE, batch=%d %s" % (
                 cfg.num_blocks, cfg.num_experts, B, ("var-len %s frames" % args.varlen) if args.varlen else "%d-frame utterances" % T)
+        # which BASELINE.json config the run IS (not which dtype it resembles)
+        full = cfg.num_blocks == 18
+        if full and cfg.weight_dtype == "f32" and cfg.num_experts == 32 and B == 1 and T == 206 and not args.varlen:
+            which = "BASELINE.json configs[1]"
+        elif full and cfg.weight_dtype == "bf16" and cfg.num_experts == 32 and B == 16 and args.varlen == "50-500":
+            which = "BASELINE.json configs[2]"
+        elif full and cfg.weight_dtype == "fp8" and cfg.num_experts == 64 and args.varlen == "50-500":
+            which = "one GPU's share of BASELINE.json configs[4]: all 64 experts local, no expert parallelism"
+        else:
+            which = "not a BASELINE.json config"
+        arith = {"f32": "fp32 (v_mfma_f32_16x16x4_f32)",
+                 "bf16": "bf16 weights / bf16 MFMA / fp32 accumulate + activations",
+                 "fp8": "%s expert weights + bf16 dense weights / fp32 accumulate + activations" % cfg.fp8_label()}[cfg.weight_dtype]
+        cpu_model = ""
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            pass
+        if cpu is not None:
+            cpu["cpu_model"] = cpu_model
         out = {"metric": metric,
                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": cfg.weight_dtype, "data": "synthetic",
-               "config": {"workload": "%d-layer %d-expert %s, batch=%dx%d frames per GPU%s, all experts local "
-                                      "(BASELINE.json configs[%d])" % (
-                                          cfg.num_blocks, cfg.num_experts,
-                                          {"f32": "fp32", "bf16": "bf16 weights / bf16 MFMA / fp32 accumulate + activations",
-                                           "fp8": "fp8 (e4m3) expert weights + bf16 dense weights / bf16 MFMA / fp32 accumulate "
-                                                  "+ activations"}[cfg.weight_dtype], B, T,
-                                          (" (lengths U[%s], %d real frames)" % (args.varlen, n_frames)) if args.varlen else "",
-                                          {"f32": 1, "bf16": 2, "fp8": 4}[cfg.weight_dtype]),
+               "config": {"workload": "%d-layer %d-expert %s, batch=%dx%d frames per GPU%s, all experts local (%s)" % (
+                              cfg.num_blocks, cfg.num_experts, arith, B, T,
+                              (" (lengths U[%s], %d real frames)" % (args.varlen, n_frames)) if args.varlen else "", which),
                           "layers": cfg.num_blocks, "experts": cfg.num_experts, "frames": T, "batch_per_gpu": B,
                           "parallelism": "replicas x%d" % world, "streams_per_gpu": len(ctxs),
-                          "latency_ms_one_stream": round(latency_ms, 4), "hip_graph": use_graph,
+                          "value_is": "%d concurrent batch-%d requests per GPU (execution contexts sharing one copy of the "
+                                      "weights); one request alone: latency_ms_one_stream" % (len(ctxs), B),
+                          "latency_ms_one_stream": round(latency_ms, 4),
+                          "frames_per_s_one_stream": round(n_frames / (latency_ms * 1e-3), 1), "hip_graph": use_graph,
                           "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
                           "routing": args.routing, "route_mode": ["staged", "fused", "split"][route],
                           "packed_rows": bool(B > 1 and eng.packed_rows())},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "roofline_expert": roofline_expert, "forward": forward, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 3
+#define M3ASR_ABI_VERSION 4
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -342,6 +342,20 @@ int m3_engine_run(m3_engine* engine, int first_stage, int last_stage, m3_stream 
  * "blocks.N.gate_idx" / "gate_value" / "mapping" / "acc_histogram", "blocks.N.out" (debug_taps only). */
 int m3_engine_buffer(const m3_engine* engine, const char* name, void** ptr, size_t* bytes);
 int m3_engine_num_kernels(const m3_engine* engine);
+/* What a stage of the prepared shape launches, for measurement (bench.py prices each stage against the roofline):
+ * `kernel` = the device kernel the stage's dispatcher picks for this shape, `launches` = kernel launches of the stage,
+ * `alg_bytes` / `flops` = algorithmic HBM bytes (operands read once, results written once) and FLOPs (2 per MAC) of one
+ * run with every padded row live; `per_row` = 1 when both scale with the live rows of a packed ragged batch;
+ * alg_bytes < 0: data-dependent (the grouped expert FFN: touched experts x weight bytes, priced by the caller from
+ * the routing taps). */
+typedef struct m3_stage_info {
+  const char* kernel;
+  int32_t launches;
+  int32_t per_row;
+  double alg_bytes;
+  double flops;
+} m3_stage_info;
+int m3_engine_stage_info(const m3_engine* engine, int index, m3_stage_info* info);
 
 #ifdef __cplusplus
 }

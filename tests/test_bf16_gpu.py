@@ -97,15 +97,39 @@ def test_linear_bf16_folded_layernorm(M, mean, std):
     assert err < 2e-2 * (1 + abs(mean) / std), float(err)
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _fused_form_from_4096_rows():
+    """The fused long-batch expert kernel is taken from 32 k rows by default; the library reads the threshold once, so it is
+    lowered for this module before the first expert call (cases >= 4096 rows with >= 64 rows per expert then use it)."""
+    import os
+    os.environ["M3_EXPERT_FUSED_MIN_ROWS"] = "4096"
+    yield
+
+
 @pytest.mark.parametrize("S,E,D,Fh,mode", [(50, 32, 512, 1024, "uniform"), (50, 32, 512, 1024, "all_one"),
                                            (200, 32, 512, 1024, "uniform"), (1090, 32, 512, 1024, "with_dropped"),
                                            (23, 4, 32, 64, "with_dropped"), (600, 64, 512, 1024, "uniform"),
                                            # >= 1024 rows: two grouped GEMMs on the LDS-tiled core (64- and 128-row tiles)
                                            (2048, 32, 512, 1024, "all_one"), (8192, 32, 512, 1024, "uniform"),
-                                           (6500, 8, 512, 1024, "with_dropped")])
+                                           (6500, 8, 512, 1024, "with_dropped"),
+                                           # the fused one-kernel form (default from 32 k rows, forced here from 4096 by
+                                           # M3_EXPERT_FUSED_MIN_ROWS, see the autouse fixture below)
+                                           # (H in registers): F split over 2 work-groups / not, ragged 128-token tiles
+                                           # (an expert with 1 row, empty experts, one expert with most rows), 64
+                                           # experts, F not a multiple of 128
+                                           (4096, 32, 512, 1024, "skewed"), (16384, 32, 512, 1024, "uniform"),
+                                           (33000, 32, 512, 1024, "with_dropped"), (9000, 64, 512, 1024, "uniform"),
+                                           (5000, 16, 512, 1088, "skewed")])
 def test_fmoe_expert_bf16(S, E, D, Fh, mode):
     rng = np.random.default_rng(S + E)
-    g = {"uniform": rng.integers(0, E, S), "all_one": np.full(S, 3), "with_dropped": rng.integers(-1, E, S)}[mode]
+    if mode == "skewed":
+        pr = np.ones(E)
+        pr[0], pr[2:6] = 0.6 * E, 0.0
+        skew = rng.choice(E, size=S, p=pr / pr.sum())
+        skew[skew == 1] = 7
+        skew[S // 2] = 1                      # expert 1: exactly one row
+    g = {"uniform": lambda: rng.integers(0, E, S), "all_one": lambda: np.full(S, 3),
+         "with_dropped": lambda: rng.integers(-1, E, S), "skewed": lambda: skew}[mode]()
     g = torch.from_numpy(g.astype(np.int32))
     x = rnd(S, D, seed=1)
     w1, b1 = rnd(E, Fh, D, seed=2, scale=D ** -0.5), rnd(E, Fh, seed=3, scale=0.1)
@@ -125,6 +149,30 @@ def test_fmoe_expert_bf16(S, E, D, Fh, mode):
     # within bf16 accuracy of the fp32 expert FFN
     y32, _, _ = ref.fmoe_expert(x.view(1, S, D), g.view(1, S, 1), w1, b1, w2, b2)
     assert float((y.cpu() - y32.view(S, D)).abs().max()) < 3e-2 * float(y32.abs().max())
+
+
+def test_fmoe_expert_bf16_position_independence_fused_form():
+    """The fused long-batch kernel: a token's result does not depend on the other tokens' VALUES (bit for bit), and
+    re-running is bit-reproducible.  Its fp32 accumulation order over the F slices depends on the token's tile index
+    inside its expert (tiles of one expert walk the slices from different starts so that they do not queue on the same
+    L2 lines), so a PERMUTED batch agrees to summation-order rounding (1e-6 of the output scale), not bit for bit."""
+    S, E, D, Fh = 6000, 32, 512, 1024
+    x = rnd(S, D, seed=1)
+    w1, b1 = rnd(E, Fh, D, seed=2, scale=D ** -0.5).to(torch.bfloat16), rnd(E, Fh, seed=3, scale=0.1)
+    w2, b2 = rnd(E, D, Fh, seed=4, scale=Fh ** -0.5).to(torch.bfloat16), rnd(E, D, seed=5, scale=0.1)
+    g = torch.randint(0, E, (S,), dtype=torch.int32, generator=torch.Generator().manual_seed(3))
+    args = [dev(t) for t in (w1, b1, w2, b2)]
+    y_all = ops.moe_expert_ffn(dev(x), dev(g), *args)
+    assert torch.equal(ops.moe_expert_ffn(dev(x), dev(g), *args), y_all)                 # run-to-run
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(4))
+    y_perm = ops.moe_expert_ffn(dev(x[perm]), dev(g[perm]), *args)
+    scale = float(y_all.abs().max())
+    assert float((y_perm.cpu() - y_all.cpu()[perm]).abs().max()) <= 2e-6 * scale
+    # other VALUES in the other rows (same routing, hence the same tiles): same rows, same bits
+    x2 = x.clone()
+    x2[1::2] = rnd(S, D, seed=9)[1::2]
+    y_mix = ops.moe_expert_ffn(dev(x2), dev(g), *args)
+    assert torch.equal(y_mix.cpu()[0::2], y_all.cpu()[0::2])
 
 
 def test_fmoe_expert_bf16_position_independence():
@@ -148,7 +196,7 @@ def test_fmoe_expert_bf16_position_independence():
 # ENGINE's expert choices (gate value = softmax probability of that expert) and the logits must agree within
 # BF16_REL of the largest logit; separately the engine's free-running choices must agree with the fp32 oracle's
 # own choices on >= 90 % of the tokens.
-BF16_REL = 3e-2
+BF16_REL = 2e-2     # measured 0.5-1.0e-2 on these cases and 0.8e-2 at 18 layers (tests/test_full_size_gpu.py)
 
 
 def _bf16_case(cfg32, seed, lengths):
@@ -193,7 +241,7 @@ def test_engine_bf16_vs_fp32_oracle(name, cfg, lengths):
         total += int(valid.sum())
         assert bool((gi[~valid] == -1).all())
     print("bf16 %s: routing agreement %d / %d" % (name, agree, total))
-    assert agree >= 0.9 * total, (agree, total)
+    assert agree >= 0.93 * total, (agree, total)
 
 
 def test_bf16_plan_round_trip_and_sizes(tmp_path):

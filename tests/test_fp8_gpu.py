@@ -96,7 +96,7 @@ def test_fmoe_expert_fp8(S, E, D, Fh, mode):
     assert float((y.cpu() - y32.view(S, D)).abs().max()) < 1e-1 * float(y32.abs().max())
 
 
-FP8_REL = 1e-1
+FP8_REL = 2e-2      # weight-only e4m3 (3 mantissa bits): measured 0.9-1.0e-2 teacher-forced
 
 
 @pytest.mark.parametrize("name,cfg,lengths", [
@@ -127,7 +127,7 @@ def test_engine_fp8_vs_fp32_oracle(name, cfg, lengths):
     print("fp8 %s: max |err| / max |logit| = %.3e (teacher-forced routing)" % (name, err))
     assert err < FP8_REL, err
     same = sum(int((forced[k].view(B, Tp)[valid] == free[k].view(B, Tp)[valid]).sum()) for k in forced)
-    assert same >= 0.85 * int(valid.sum()) * cfg.num_blocks
+    assert same >= 0.93 * int(valid.sum()) * cfg.num_blocks
 
 
 def test_fp8_plan_round_trip(tmp_path):
