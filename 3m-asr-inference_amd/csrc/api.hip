@@ -126,6 +126,16 @@ int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_
   return launch_moe_combine(rows, 1, mapping, nullptr, gate_value, nullptr, resid, alpha, ln_gamma, ln_beta, ln_eps, out,
                             S, idim, (hipStream_t)stream);
 }
+int m3_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_histogram, int S, int world, int e_loc,
+                   int capacity, int32_t* map_send, void* wire, int row_bytes, m3_stream stream) {
+  M3_REQUIRE(gate_idx && mapping && acc_histogram && map_send && wire, "ep_send_map: null pointer");
+  return launch_ep_send_map(gate_idx, mapping, acc_histogram, S, world, e_loc, capacity, map_send, wire, row_bytes,
+                            (hipStream_t)stream);
+}
+int m3_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv, m3_stream stream) {
+  M3_REQUIRE(wire && gate_recv, "ep_recv_gate: null pointer");
+  return launch_ep_recv_gate(wire, world, e_loc, capacity, row_bytes, gate_recv, (hipStream_t)stream);
+}
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
                     int32_t* idx, float* value, m3_stream stream) {
   return launch_softmax_top1(logits, ld, len, rows_per_batch, S, width, idx, value, (hipStream_t)stream);

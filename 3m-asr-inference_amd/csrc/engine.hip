@@ -245,10 +245,10 @@ struct Plan {
   size_t bytes;
 };
 
-// the blocks run on packed rows: B > 1 (or forced), one rank, no per-block taps (they are read as (B, T', D)), staged route
+// the blocks run on packed rows: B > 1 (or forced), no per-block taps (they are read as (B, T', D)), staged route
 bool use_packed_rows(const m3_engine_config& c, int B) {
   if (c.packed_rows < 0 || (c.packed_rows == 0 && B <= 1)) return false;
-  return c.ep_world_size <= 1 && !c.debug_taps && c.fuse_route == 0 && B <= 1024;
+  return !c.debug_taps && c.fuse_route == 0 && B <= 1024;   // (expert-parallel ranks too: rows past the live count never travel)
 }
 
 Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {

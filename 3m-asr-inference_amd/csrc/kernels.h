@@ -73,6 +73,12 @@ int launch_moe_route(const float* x, int ldx, int D, const float* wx, const floa
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 
+// ---- expert-parallel exchange bookkeeping on the device (ep_exchange.hip) ----
+int launch_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
+                       int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream);
+int launch_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv,
+                        hipStream_t stream);
+
 // ---- grouped expert FFN (moe_expert.hip) ----
 constexpr int kExpertSlice = 64;  // hidden units per workgroup (16 per wave); m3asr/plan.py EXPERT_SLICE must match
 size_t expert_ffn_slab_bytes(int S, int D, int F);

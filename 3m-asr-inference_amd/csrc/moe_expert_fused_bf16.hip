@@ -355,12 +355,9 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_bf16_kernel(
 }
 
 // ---- host side ----
-static int fused_min_rows() {
-  static const int v = [] {
-    const char* e = getenv("M3_EXPERT_FUSED_MIN_ROWS");
-    return e ? atoi(e) : 32768;   // measured cross-over against the two-GEMM form: 16 k rows lose, 64 k win
-  }();
-  return v;
+static int fused_min_rows() {   // read on every call (a getenv per launch is noise): tests lower it per module
+  const char* e = getenv("M3_EXPERT_FUSED_MIN_ROWS");
+  return e ? atoi(e) : 32768;     // measured cross-over against the two-GEMM form: 16 k rows lose, 64 k win
 }
 
 // the F range is split over 2 work-groups while the token tiles alone would leave CUs idle

@@ -140,6 +140,8 @@ SIGNATURES = {
     "m3_engine_buffer": (_i, [_vp, _cp, _P(_vp), _P(_sz)]),
     "m3_engine_num_kernels": (_i, [_vp]),
     "m3_engine_stage_info": (_i, [_vp, _i, _vp]),
+    "m3_ep_send_map": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "m3_ep_recv_gate": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -51,6 +51,33 @@ def moe_local_scatter(x, mapping, n_rows):
     return out
 
 
+def moe_local_scatter_into(x, mapping, out):
+    """out[mapping[s]] = x[s] for mapping[s] >= 0, into a caller-owned buffer (rows of out not hit keep their content)."""
+    lib = _lib.load()
+    S, row_bytes = x.shape[0], x[0].numel() * x.element_size()
+    check(lib.m3_moe_local_scatter(_p(x), _i32(mapping), S, row_bytes, _p(out), _stream()), "m3_moe_local_scatter")
+    return out
+
+
+def ep_send_map(gate_idx, mapping, acc, world, e_loc, capacity, map_send, wire):
+    """Expert-parallel send plan on the device (m3_ep_send_map): fills map_send[S] and the header rows of `wire`
+    [world, 1 + capacity, D]."""
+    lib = _lib.load()
+    S = gate_idx.numel()
+    row_bytes = wire.shape[-1] * wire.element_size()
+    check(lib.m3_ep_send_map(_i32(gate_idx.reshape(-1)), _i32(mapping), _i32(acc), S, world, e_loc, capacity, _p(map_send),
+                             _p(wire), row_bytes, _stream()), "m3_ep_send_map")
+    return map_send
+
+
+def ep_recv_gate(wire, world, e_loc, capacity, gate_recv):
+    """Local expert id of every received wire row (m3_ep_recv_gate)."""
+    lib = _lib.load()
+    row_bytes = wire.shape[-1] * wire.element_size()
+    check(lib.m3_ep_recv_gate(_p(wire), world, e_loc, capacity, row_bytes, _p(gate_recv), _stream()), "m3_ep_recv_gate")
+    return gate_recv
+
+
 def moe_local_gather(buf, mapping):
     lib = _lib.load()
     S = mapping.numel()
@@ -65,7 +92,7 @@ def moe_expert_workspace_size(S, E, D, F):
 
 
 def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None,
-                   w1_scale=None, w2_scale=None):
+                   w1_scale=None, w2_scale=None, out=None):
     """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue (gate, residual, LayerNorm).
     The expert weights pick the kernel family: fp32; bf16 (bf16 MFMA, fp32 accumulate); e4m3 with per-row scales
     w1_scale [E,F] / w2_scale [E,D] (dequantised to bf16 at the MFMA input).  Biases are fp32 in every mode."""
@@ -75,7 +102,7 @@ def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alp
     E, F = w1.shape[0], w1.shape[1]
     if workspace is None:
         workspace = torch.empty(max(moe_expert_workspace_size(S, E, D, F), 1), dtype=torch.uint8, device=x.device)
-    y = torch.empty_like(x)
+    y = out if out is not None else torch.empty_like(x)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     gate = _f32(gate_value.reshape(-1) if gate_value is not None else None)
     tail = (S, E, D, F, gate, _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),

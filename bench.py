@@ -84,6 +84,13 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 runs (nccl = RCCL; gloo: rehearsal of the multi-rank path "
                          "on a box with fewer GPUs than ranks -- ranks then share devices)")
+    ap.add_argument("--ep", action="store_true",
+                    help="expert-parallel mode (BASELINE.json configs[3] / [4]): the experts of every layer are sharded "
+                         "E / N per rank, every rank keeps --batch utterances, tokens travel by all-to-all (RCCL with "
+                         "--dist-backend nccl); value = frames of all ranks / max-over-ranks time")
+    ap.add_argument("--no-ep-probe", action="store_true",
+                    help="N > 1 replica runs end with a short expert-parallel forward over the same process group, reported "
+                         "on stderr and in gpurun_out/ep_probe_nN.json AFTER the JSON line; this switches it off")
     ap.add_argument("--pmc-safe", action="store_true",
                     help="for `rocprofv3 --pmc ... -- python3 bench.py --pmc-safe`: one execution context and 4 host threads "
                          "(the counter-collection abort of round 1 followed the host thread count, DESIGN.md 6)")
@@ -144,6 +151,82 @@ def balance_router(eng, cpu_weights):
     eng.stream.synchronize()
 
 
+def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, varlen, frames, balanced=True):
+    """Expert-parallel forwards (m3asr/ep.py): experts sharded E / world per rank, batch sharded B per rank, two fixed-shape
+    all-to-alls per MoE layer, no host synchronisation inside a forward.  Returns a dict (rank 0: the measurement)."""
+    from m3asr.config import EncoderConfig
+    from m3asr.engine import Engine
+    from m3asr.ep import ExpertParallelEncoder
+    E, L = args.experts, args.layers
+    assert E % world == 0, "--experts %d must divide over %d ranks" % (E, world)
+    full = EncoderConfig(num_blocks=L, num_experts=E, weight_dtype=wdt)
+    rng = np.random.default_rng(4321 + rank)
+    if varlen:
+        lo, hi = (int(v) for v in varlen.split("-"))
+        lengths = rng.integers(lo, hi + 1, B)
+        lengths[0] = hi
+        T = hi
+    else:
+        lengths, T = np.full(B, frames), frames
+    feat = torch.from_numpy(rng.random((B, T, full.input_dim), dtype=np.float32)).to(dev)
+    feat_len = torch.from_numpy(lengths.astype(np.int32)).view(1, B).to(dev)
+    on_host = world > 1 and dist.get_backend() == "gloo"
+    if balanced:
+        # load-balanced synthetic routers: calibrated on rank 0's utterances with an all-experts-local engine, then the
+        # 18 router matrices are broadcast (dense weights are replicated across expert-parallel ranks)
+        keys = ["blocks.%d.feed_forward.router_weights" % i for i in range(L)]
+        if rank == 0:
+            cal = Engine.from_state_dict(full, weights_full, device=dev, fuse_route=False)
+            cal.bind(feat, feat_len)
+            balance_router(cal, weights_full)
+            del cal
+            torch.cuda.empty_cache()
+        if world > 1:
+            for k in keys:
+                t = weights_full[k].contiguous() if on_host else weights_full[k].to(dev).contiguous()
+                dist.broadcast(t, src=0)
+                weights_full[k] = t.cpu()
+    cfg = EncoderConfig(num_blocks=L, num_experts=E // world, ep_world_size=world, ep_rank=rank, weight_dtype=wdt)
+    eng = Engine.from_state_dict(cfg, weights_full, device=dev, bf16_activations=False)
+    ep = ExpertParallelEncoder(eng)
+    ep.bind(feat, feat_len)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        ep.enqueue()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ep.enqueue()
+    eng.stream.synchronize()
+    sync()
+    dt = time.perf_counter() - t0
+    frames_all = torch.tensor([float(lengths.sum())], dtype=torch.float64, device="cpu" if (on_host or world == 1) else dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=frames_all.device)
+    if world > 1:
+        dist.all_reduce(frames_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    _, S, D, bufs = ep._bound
+    touched = []
+    for li in range(L):
+        g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
+        touched.append(len(np.unique(g[g >= 0])))
+    return {"value": float(frames_all.item()) / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "frames_per_step_all_ranks": int(frames_all.item()), "batch_per_gpu": B, "padded_frames": T,
+            "experts_per_gpu": E // world, "weight_dtype": wdt, "rows_per_rank": S, "packed_rows": bool(B > 1 and eng.packed_rows()),
+            "wire": {"capacity_rows": bufs.cap, "bytes_per_exchange_per_rank": int(bufs.wire_a.numel() * 4),
+                     "collectives_per_forward": 2 * L, "host_syncs_per_forward": 0,
+                     "backend": (dist.get_backend() if world > 1 else "none (one rank: local copy)")},
+            "global_experts_touched_by_rank0_tokens_mean": round(float(np.mean(touched)), 2),
+            "kernels_per_forward_native_stages": eng.num_kernels()}
+
+
 def main():
     args = parse()
     if args.pmc_safe or _profiler_attached():
@@ -187,6 +270,31 @@ def main():
 
     from m3asr.engine import Engine
 
+    if args.ep:
+        r = run_ep(args, rank, world, dev, dist if world > 1 else None, weights, args.steps, args.warmup, args.weight_dtype,
+                   args.batch, args.varlen, args.frames, balanced=args.routing == "balanced")
+        if rank == 0:
+            full18 = args.layers == 18
+            if full18 and args.weight_dtype == "bf16" and args.experts == 32 and world == 8 and args.batch == 2 and args.varlen == "50-500":
+                which = "BASELINE.json configs[3]"
+            elif full18 and args.weight_dtype == "fp8" and args.experts == 64 and world == 8 and args.batch == 8 and args.varlen == "50-500":
+                which = "BASELINE.json configs[4] (fp8 = e4m3 weight-only experts, bf16 MFMA)"
+            else:
+                which = "not a BASELINE.json config (same path at another size)"
+            out = {"metric": "encoder frames/sec, %dLx%de Conformer-MoE, expert parallel, batch=%d per GPU %s" % (
+                       args.layers, args.experts, args.batch, ("var-len %s frames" % args.varlen) if args.varlen else "%d-frame utterances" % args.frames),
+                   "value": round(r["value"], 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": args.weight_dtype, "data": "synthetic",
+                   "config": {"workload": "%d-layer %d-expert %s, expert-parallel %d experts/GPU x %d GPU, batch %d per GPU (%s)" % (
+                                  args.layers, args.experts, args.weight_dtype, r["experts_per_gpu"], world, args.batch, which),
+                              "parallelism": "ep%d x dp%d" % (world, world), "hip_graph": False, **{k: v for k, v in r.items() if k not in ("value", "ms_per_step", "steps", "warmup")}},
+                   "roofline": None, "cpu_baseline": None}
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     # synthetic input: U[0,1) features as data/generate_trtexec_inputs.py:7 of the reference; each rank its own utterance
     rng = np.random.default_rng(1234 + rank)
     B, T = args.batch, args.frames
@@ -214,7 +322,7 @@ def main():
         del eng
         torch.cuda.empty_cache()
         eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed)
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+    if not ((rank == 0 and world == 1 and not args.no_cpu_baseline) or (world > 1 and not args.no_ep_probe)):
         weights = None
     eng.bind(feat, feat_len)
     eng.forward(use_graph=False)
@@ -470,6 +578,28 @@ def main():
                           "packed_rows": bool(B > 1 and eng.packed_rows())},
                "roofline": roofline, "roofline_expert": roofline_expert, "forward": forward, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
+    if world > 1 and not args.no_ep_probe and weights is not None:
+        # After the headline line: a short expert-parallel run over the same process group (configs[3]-shaped: bf16, 2
+        # ragged utterances per GPU, experts sharded E / N), so that a multi-GPU run also exercises the all-to-all path.
+        # Reported on stderr and in gpurun_out/; guarded: whatever happens here, the process ends with exit code 0.
+        import threading
+        threading.Timer(150.0, lambda: os._exit(0)).start()
+        try:
+            if args.experts % world == 0:
+                r = run_ep(args, rank, world, dev, dist, weights, 10, 2, "bf16", 2, "50-500", 0, balanced=True)
+                if rank == 0:
+                    r["what"] = "expert-parallel probe after the replica benchmark: %dL/%de bf16, %d experts/GPU, 2 utterances U[50,500] per GPU" % (
+                        args.layers, args.experts, args.experts // world)
+                    r["n_gpus"] = world
+                    print("ep_probe " + json.dumps(r), file=sys.stderr, flush=True)
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", "ep_probe_n%d.json" % world), "w") as f:
+                        json.dump(r, f)
+        except BaseException as ex:      # noqa: BLE001 -- the probe must never take the benchmark's exit code with it
+            print("ep_probe failed on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

@@ -138,6 +138,20 @@ int m3_moe_expert_ffn_fp8(const float* x, const int32_t* gate_idx, const void* w
 int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid,
                    float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S,
                    int idim, m3_stream stream);
+/* Expert-parallel exchange without a host round trip (replaces the host logic of FastMoE's moe_prepare_forward /
+ * MOEScatter / MOEGather, trainer_3m_fix/fmoe/functions.py:13-52,63-86,175-199, which reads the counts back to size its
+ * all-to-all-v).  The wire buffer has a FIXED shape [world][1 + capacity][row_bytes]: chunk j = what this rank sends to
+ * (after the equal-split all-to-all: received from) rank j = one header row with the e_loc row counts of the chunk
+ * (int32: the count exchange rides in the payload) + up to `capacity` rows sorted by rank j's local expert id.
+ *   m3_ep_send_map : from the local index step (gate_idx = GLOBAL expert id or -1, mapping, acc_histogram over
+ *                    world * e_loc experts) -> map_send[s] = wire row of token s (-1: dropped) and the headers written
+ *                    into `wire`; local_scatter(x, map_send) then fills the payload, and the reply comes back at the same
+ *                    row.  capacity >= S (a rank may send everything to one peer).
+ *   m3_ep_recv_gate: from the headers of the received chunks -> gate_recv[world * (1 + capacity)] = local expert id of
+ *                    every received wire row (-1: header / unused), the gate input of m3_moe_expert_ffn. */
+int m3_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_histogram, int S, int world, int e_loc,
+                   int capacity, int32_t* map_send, void* wire, int row_bytes, m3_stream stream);
+int m3_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv, m3_stream stream);
 /* Replaces ComputeSoftmaxAndTop1 (softmax_topk_kernel.cu:88-120): logits [S][ld] -> idx[S], value[S];
  * frames t >= len[b] (t = s % rows_per_batch, b = s / rows_per_batch) get idx -1 / value 0; len may be NULL. */
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,

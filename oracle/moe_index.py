@@ -77,3 +77,35 @@ def ep_exchange_counts_ref(local_counts_per_rank, world, e_loc):
     gc = lc.transpose(1, 0, 2).copy()                                     # [owner][src][i]
     fwd = gc.sum(1)
     return gc.reshape(world, world * e_loc), fwd
+
+
+def ep_send_map_ref(gate_idx, mapping, acc, world, e_loc, capacity, row_words):
+    """CPU statement of m3_ep_send_map (3m-asr-inference_amd/csrc/ep_exchange.hip): wire row of every token and the
+    header rows (int32 counts per local expert of the destination rank) of a [world, 1 + capacity, row_words] wire."""
+    S = len(gate_idx)
+    map_send = np.full(S, -1, dtype=np.int32)
+    headers = np.zeros((world, 1 + capacity, row_words), dtype=np.int32)
+    for j in range(world):
+        for i in range(e_loc):
+            headers[j, 0, i] = acc[j * e_loc + i + 1] - acc[j * e_loc + i]
+    for s in range(S):
+        g = int(gate_idx[s])
+        if 0 <= g < world * e_loc:
+            j = g // e_loc
+            off = int(mapping[s]) - int(acc[j * e_loc])
+            map_send[s] = j * (capacity + 1) + 1 + off if off < capacity else -1
+    return map_send, headers
+
+
+def ep_recv_gate_ref(headers, world, e_loc, capacity):
+    """CPU statement of m3_ep_recv_gate: local expert id of every wire row of the received chunks (-1: header row /
+    unused capacity); headers[j, 0, :e_loc] = rows from rank j per local expert."""
+    gate = np.full((world, 1 + capacity), -1, dtype=np.int32)
+    for j in range(world):
+        t = 0
+        for i in range(e_loc):
+            c = max(int(headers[j, 0, i]), 0)
+            c = min(c, capacity - t)
+            gate[j, 1 + t: 1 + t + c] = i
+            t += c
+    return gate.reshape(-1)

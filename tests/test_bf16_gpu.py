@@ -99,11 +99,16 @@ def test_linear_bf16_folded_layernorm(M, mean, std):
 
 @pytest.fixture(autouse=True, scope="module")
 def _fused_form_from_4096_rows():
-    """The fused long-batch expert kernel is taken from 32 k rows by default; the library reads the threshold once, so it is
-    lowered for this module before the first expert call (cases >= 4096 rows with >= 64 rows per expert then use it)."""
+    """The fused long-batch expert kernel is taken from 32 k rows by default; the library reads the threshold on every call, so it is
+    lowered for this module (cases >= 4096 rows with >= 64 rows per expert then use it)."""
     import os
+    old = os.environ.get("M3_EXPERT_FUSED_MIN_ROWS")
     os.environ["M3_EXPERT_FUSED_MIN_ROWS"] = "4096"
     yield
+    if old is None:
+        del os.environ["M3_EXPERT_FUSED_MIN_ROWS"]
+    else:
+        os.environ["M3_EXPERT_FUSED_MIN_ROWS"] = old
 
 
 @pytest.mark.parametrize("S,E,D,Fh,mode", [(50, 32, 512, 1024, "uniform"), (50, 32, 512, 1024, "all_one"),

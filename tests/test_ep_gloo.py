@@ -1,7 +1,8 @@
 """Expert-parallel exchange on CPU with the gloo backend, world_size 2 (the N>1 path of §⑤): every rank routes its own
 tokens over experts sharded 4 per rank; the result must equal the single-process result with all experts local.
 Compute steps use the CPU oracle as the backend (the product backend is HipBackend = libm3asr_hip.so); what is under
-test here is the host logic: counts, split sizes, wire order, reassembly."""
+test here is the host logic and the wire format: fixed-shape chunks [world][1 + capacity][D] with the row counts in a
+header row (the count exchange rides in the payload), equal-split all-to-all both ways, wire order, reassembly."""
 import os
 import socket
 
@@ -14,20 +15,36 @@ import torch.nn.functional as F
 
 from m3asr.ep import ep_moe_layer
 from oracle.encoder_ref import fmoe_expert
-from oracle.moe_index import moe_index_ref, local_scatter_ref, ep_exchange_counts_ref
+from oracle.moe_index import moe_index_ref, local_scatter_ref, ep_exchange_counts_ref, ep_send_map_ref, ep_recv_gate_ref
 
 
 class OracleBackend:
+    """numpy / torch statements of the device steps (oracle/moe_index.py, oracle/encoder_ref.py)."""
+
     def index(self, gate_idx, n_total):
         m, a = moe_index_ref(gate_idx.numpy(), n_total)
         return torch.from_numpy(m), torch.from_numpy(a), None
 
-    def scatter(self, x, mapping, n_rows):
-        return torch.from_numpy(local_scatter_ref(x.numpy(), mapping.numpy(), n_rows))
+    def send_map(self, gate_idx, mapping, acc, world, e_loc, cap, map_send, wire):
+        m, hdr = ep_send_map_ref(gate_idx.numpy(), mapping.numpy(), acc.numpy(), world, e_loc, cap, wire.shape[-1])
+        map_send.copy_(torch.from_numpy(m))
+        wire.view(torch.int32)[:, 0, :e_loc] = torch.from_numpy(hdr[:, 0, :e_loc])
+        return map_send
 
-    def expert_ffn(self, rows, gate_local, w):
+    def scatter_into(self, x, map_send, wire):
+        flat = wire.view(-1, wire.shape[-1])
+        keep = map_send >= 0
+        flat[map_send[keep].long()] = x[keep]
+        return wire
+
+    def recv_gate(self, wire, world, e_loc, cap, gate_recv):
+        gate_recv.copy_(torch.from_numpy(ep_recv_gate_ref(wire.view(torch.int32).numpy(), world, e_loc, cap)))
+        return gate_recv
+
+    def expert_ffn(self, rows, gate_local, w, out, workspace=None):
         y, _, _ = fmoe_expert(rows.unsqueeze(0), gate_local.view(1, -1, 1), w["w1"], w["b1"], w["w2"], w["b2"])
-        return y[0]
+        out.copy_(y[0])
+        return out
 
     def combine(self, rows_sorted, mapping, gate_value, resid, alpha, ln, out=None):
         m = mapping.long()
@@ -101,3 +118,33 @@ def test_count_exchange_contract():
                 assert gc[r, j * e_loc + i] == np.sum(gates[j] == r * e_loc + i)
         assert np.array_equal(fwd[r], gc[r].reshape(world, e_loc).sum(0))
     assert fwd.sum() == sum(len(g) for g in gates)
+
+
+def test_wire_format_contract():
+    """m3_ep_send_map / m3_ep_recv_gate (oracle statements): headers carry the per-local-expert counts, every token gets a
+    distinct wire row inside its owner's chunk in sorted order, dropped tokens get none; the receiver labels exactly the
+    announced rows, in local-expert order, and nothing beyond the capacity whatever the header says."""
+    world, e_loc, S, words = 4, 2, 23, 8
+    rng = np.random.default_rng(5)
+    gate = rng.integers(-1, world * e_loc, S).astype(np.int32)
+    mapping, acc = moe_index_ref(gate, world * e_loc)
+    cap = S
+    map_send, hdr = ep_send_map_ref(gate, mapping, acc, world, e_loc, cap, words)
+    live = gate >= 0
+    assert (map_send[~live] == -1).all() and len(set(map_send[live])) == int(live.sum())
+    for s_ in np.nonzero(live)[0]:
+        j, row = divmod(int(map_send[s_]), cap + 1)
+        assert j == gate[s_] // e_loc and row >= 1
+    for j in range(world):
+        for i in range(e_loc):
+            assert hdr[j, 0, i] == np.sum(gate == j * e_loc + i)
+    # a receiver that got chunk j from every rank r: here simply feed the headers back
+    g = ep_recv_gate_ref(hdr, world, e_loc, cap).reshape(world, cap + 1)
+    for j in range(world):
+        assert g[j, 0] == -1
+        want = np.repeat(np.arange(e_loc), hdr[j, 0, :e_loc])
+        assert np.array_equal(g[j, 1:1 + len(want)], want) and (g[j, 1 + len(want):] == -1).all()
+    bad = hdr.copy()
+    bad[0, 0, 0] = 10 ** 6                       # a corrupt count must not label rows past the chunk
+    g2 = ep_recv_gate_ref(bad, world, e_loc, cap).reshape(world, cap + 1)
+    assert (g2[0, 1:] == 0).all() and g2.shape[1] == cap + 1

@@ -34,6 +34,53 @@ def test_ep_world1_equals_fused_engine():
     assert torch.allclose(fused, staged, rtol=1e-4, atol=1e-4)
 
 
+def test_ep_world1_on_packed_rows_equals_engine():
+    """The device-side exchange works on the packed row layout of ragged batches (rows past the live count carry
+    gate_idx -1 and never reach the wire): with one rank it reproduces the packed engine bit for bit, fp32."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=4)
+    feat = torch.rand(4, 206, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
+    fl = torch.tensor([[206, 77, 150, 33]], dtype=torch.int32).cuda()
+    eng = Engine.from_state_dict(cfg, w, fuse_route=False)
+    want = eng(feat, fl).clone()
+    assert eng.packed_rows()
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False))
+    got = ep.forward(feat, fl)
+    assert ep.eng.packed_rows()
+    assert torch.equal(got, want)
+    # a second forward on the same binding re-uses the buffers (nothing is allocated or synchronised per layer)
+    assert torch.equal(ep.forward(feat, fl), want)
+
+
+def test_bench_expert_parallel_rehearsal_two_ranks_one_gpu(tmp_path):
+    """bench.py --ep with 2 ranks sharing this GPU (gloo transport staged through the host; RCCL refuses two ranks on one
+    device): the expert-parallel benchmark path end to end -- sharded plan, router broadcast, fixed-shape exchange, JSON
+    line -- on a 2-layer model; and the replica mode's expert-parallel probe after the headline line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--layers", "2",
+            "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run(base + ["--ep", "--weight-dtype", "bf16", "--batch", "2", "--varlen", "50-500"], capture_output=True,
+                       text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["experts_per_gpu"] == 16
+    assert line["config"]["wire"]["host_syncs_per_forward"] == 0 and line["config"]["wire"]["collectives_per_forward"] == 4
+    r = subprocess.run(base + ["--streams", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "replicas x2"
+    assert "ep_probe {" in r.stderr, r.stderr[-2000:]
+
+
 def test_ep_world1_bf16_equals_engine():
     """16-bit mode (BASELINE.json configs[3]: bf16 expert parallel): the EP driver feeds bf16 expert weights to
     m3_moe_expert_ffn_bf16; with one rank it must reproduce the bf16 engine bit for bit (same kernels, same order),
@@ -63,7 +110,7 @@ def _worker(rank, world, port, out_dir, wdt):
     T = 90 - 7 * rank
     feat = torch.randn(2, T, cfg.input_dim, generator=g)
     fl = torch.tensor([[T, T - 20]], dtype=torch.int32)
-    eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path, padded rows
+    eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path; B = 2: packed rows
     out = ExpertParallelEncoder(eng).forward(feat.cuda(), fl.cuda()).cpu()
     # reference: all experts local (fp32: the CPU oracle; bf16: the single-rank engine of the same precision, whose row
     # results are position independent)
