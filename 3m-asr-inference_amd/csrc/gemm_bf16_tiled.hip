@@ -401,6 +401,13 @@ int init_gemm_bf16_tiled_kernels() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(64, 64, 128)));
   M3_TILED_FOR_ALL(M3_TILED_ATTR)
 #undef M3_TILED_ATTR
+#define M3_THIN_ATTR(G_, L_)                                                                                       \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<32, 64, 128, G_, false, L_, 0>,             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(32, 64, 128)));      \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<32, 64, 128, G_, false, L_, 0, false, true>, \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(32, 64, 128)));
+  M3_THIN_ATTR(true, true) M3_THIN_ATTR(true, false) M3_THIN_ATTR(false, true) M3_THIN_ATTR(false, false)
+#undef M3_THIN_ATTR
 #define M3_GRP_ATTR(BM_, BN_, BK_, P_)                                                                            \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, P_>,  \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(BM_, BN_, BK_)))
@@ -429,7 +436,13 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
   const int Nout = glu ? p.N / 2 : p.N;
   M3_REQUIRE(!(conv && (glu || ln)), "gemm_bf16w: conv mode supports neither GLU nor LayerNorm");
   const bool big = (long)cdiv(p.M, 128) * cdiv(p.N, 128) >= 200;
-  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+  // few 64 x 64 tiles (a ragged batch of ~1000 live rows x a 512- or 1024-wide output: 136-272 live tiles on 256 CUs, each
+  // a chain of memory round trips): 32-row tiles double the work-groups.  Measured at configs[2] (M3_TILED_THIN_BELOW=600):
+  // one context alone 3.94 -> 3.72 ms, four contexts 2.42 -> 2.31 M frames/s (W tiles are fetched twice as often) -- a
+  // latency / throughput trade, off by default
+  static const int thin_below = [] { const char* e = getenv("M3_TILED_THIN_BELOW"); return e ? atoi(e) : 0; }();
+  const bool thin = !big && !conv && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < thin_below;
+  const int bm = big ? 128 : (thin ? 32 : 64), bn = big ? 128 : 64;
   p.m_tiles = cdiv(p.M, bm);
   p.n_tiles = glu ? cdiv(Nout, bn / 2) : cdiv(p.N, bn);
   dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);   // row tiles in groups of 8 (one per XCD), see the kernel
@@ -443,7 +456,15 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
     else if (big)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>), grid, dim3(256),                    \
                          tiled_lds_bytes(128, 128, 64), stream, p);                                                  \
-    else if (p.a_bf16)                                                                                               \
+    else if (thin && p.a_bf16) {                                                                                     \
+      if constexpr (!C_)                                                                                             \
+        hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<32, 64, 128, G_, false, L_, 0, false, true>), grid, dim3(256),   \
+                           tiled_lds_bytes(32, 64, 128), stream, p);                                                 \
+    } else if (thin) {                                                                                               \
+      if constexpr (!C_)                                                                                             \
+        hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<32, 64, 128, G_, false, L_, 0>), grid, dim3(256),                \
+                           tiled_lds_bytes(32, 64, 128), stream, p);                                                 \
+    } else if (p.a_bf16)                                                                                             \
       hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<64, 64, 128, G_, C_, L_, 0, false, true>), grid, dim3(256),        \
                          tiled_lds_bytes(64, 64, 128), stream, p);                                                   \
     else                                                                                                             \
