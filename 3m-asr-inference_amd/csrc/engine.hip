@@ -46,6 +46,7 @@ struct BlockW {
   Lin router_x;                     // w: [E][D] x-half with norm_ff folded (+ wsum, bias)  (fused route path)
   const float *ew1 = nullptr, *eb1 = nullptr, *ew2 = nullptr, *eb2 = nullptr;
   const float *es1 = nullptr, *es2 = nullptr;   // fp8 experts: per-row scales [E][F], [E][D]
+  float h_scale = 0.f;                          // fp8 arithmetic: static scale of the hidden activations (0 = weight-only)
 };
 
 struct SubW { const float* c1w; const float* c1b; const float* c2w; const float* c2b; Lin out; };
@@ -198,6 +199,14 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
     if (c.weight_dtype == M3_FP8) {
       GET(b->es1, p + "feed_forward.experts.w_1.scale", E * F);
       GET(b->es2, p + "feed_forward.experts.w_2.scale", E * D);
+      if (c.fp8_activations) {          // the calibrated scale of H: one fp32 number per layer, read once at set-up
+        const float* hs = nullptr;
+        GET(hs, p + "feed_forward.experts.h_scale", 1);
+        if (hipMemcpy(&b->h_scale, hs, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess || !(b->h_scale > 0.f)) {
+          set_error("engine: '%sfeed_forward.experts.h_scale' must hold one positive number", p.c_str());
+          return false;
+        }
+      }
     }
     GET(b->eb1, p + "feed_forward.experts.w_1.bias", E * F);
     GETE(b->ew2, p + "feed_forward.experts.w_2.weight_sliced", E * D * F);
@@ -548,10 +557,11 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     }
     const bool e16 = c.weight_dtype != M3_F32, e8 = c.weight_dtype == M3_FP8;
     const float *es1 = w.es1, *es2 = w.es2;
-    const int wmode = e8 ? 2 : (e16 ? 1 : 0);
+    const float h_scale = w.h_scale;
+    const int wmode = e8 ? (h_scale > 0.f ? 3 : 2) : (e16 ? 1 : 0);
     const int elaunches = e16 ? expert_ffn_w16_launches(wmode, S, E, D, F) : (expert_ffn_f32_tiled(S, E, D, F) ? 2 : 1);
     add_stage(e, pfx + "moe_local.expert", elaunches, [=](hipStream_t s) {
-      if (e8) return launch_expert_ffn_w8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, mw.slab, s);
+      if (e8) return launch_expert_ffn_w8a8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, mw.slab, s);
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     }, stage_info(e16 ? expert_ffn_w16_kernel(wmode, S, E, D, F)
@@ -560,7 +570,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     }
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
     const bool e16c = c.weight_dtype != M3_F32;
-    const int wmode_c = c.weight_dtype == M3_FP8 ? 2 : 1;
+    const int wmode_c = c.weight_dtype == M3_FP8 ? (w.h_scale > 0.f ? 3 : 2) : 1;
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_w16_rows(wmode_c, mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_w16_slices(wmode_c, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
@@ -607,6 +617,7 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
     return fail("engine_create: weight_dtype must be f32, bf16 or fp8");
   if (c.weight_dtype == M3_FP8 && (c.attention_dim % 64 || c.hidden_units % 64))
     return fail("engine_create: fp8 experts need attention_dim and hidden_units that are multiples of 64");
+  if (c.fp8_activations && c.weight_dtype != M3_FP8) return fail("engine_create: fp8_activations needs weight_dtype fp8");
   if (c.weight_dtype != M3_F32) {
     if (c.fuse_route) return fail("engine_create: fuse_route is fp32-only");
     if (c.attention_dim % 32 || c.hidden_units % 64 || c.embed_linear_units % 32)
@@ -690,6 +701,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_fused_bf16_kernels()) return rc;
+  if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);

@@ -122,6 +122,18 @@ int init_expert_ffn_fused_bf16_kernels();
 int launch_expert_ffn_fused_bf16(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
                                  int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* ybuf,
                                  hipStream_t stream);
+// fp8 arithmetic (e4m3 weights x e4m3 activations, fp8 MFMA), long batches (D = 512): moe_expert_fused_fp8.hip.
+// wmode 3 in the helpers above = "fp8 weights + fp8 activations where this kernel applies, else the weight-only form"
+bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F);
+int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F);
+int init_expert_ffn_fused_fp8_kernels();
+int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
+                                const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
+                                float h_scale, float* ybuf, hipStream_t stream);
+// fp8 weights, dispatcher: h_scale > 0 asks for fp8 activations (taken where the fused kernel applies)
+int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
+                           const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
+                           float h_scale, float* slab, hipStream_t stream);
 // long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
 int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                                   int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced,

@@ -44,7 +44,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
         "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
-        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows")]
+        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
@@ -94,6 +94,9 @@ SIGNATURES = {
                                     _vp, _sz, _vp]),
     "m3_moe_expert_ffn_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                    _vp, _sz, _vp]),
+    "m3_moe_expert_ffn_fp8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
+                                     _vp, _sz, _vp]),
+    "m3_moe_expert_ffn_fp8a8_active": (_i, [_i, _i, _i, _i]),
     "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "m3_linear": (_i, [_P(LinearDesc), _vp]),

@@ -37,10 +37,17 @@ class EncoderConfig:
     # fp32) = the reference's --fp16 / plugin_data_type 1 (builder.py:160, builder_helper.py:47-57); "fp8" = bf16 dense
     # weights + e4m3 expert weights with per-row scales, dequantised to bf16 at the MFMA input (the --int8 slot of the reference)
     weight_dtype: str = "f32"
+    # weight_dtype "fp8" only: fp8 ARITHMETIC (e4m3 x e4m3 MFMA) in the grouped expert FFN of long batches -- rows quantised
+    # with a per-row dynamic scale, H with the calibrated per-layer scale "blocks.N.feed_forward.experts.h_scale" of the
+    # plan (m3asr/calibrate.py) -- the reference's --int8 slot (builder.py:39-49, builder_helper.py:109-123)
+    fp8_activations: bool = False
     log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
 
     def fp8_label(self):
         """What the fp8 mode of this config computes in (for reports: a weight-only mode must not read as fp8 MFMA)."""
+        if self.fp8_activations:
+            return ("fp8 arithmetic (e4m3 weights x e4m3 activations, v_mfma_f32_32x32x16_fp8_fp8) in the grouped expert FFN where "
+                    "the fused fp8 kernel applies, e4m3 weight-only (W8A16) elsewhere")
         return "fp8 e4m3 weight-only (W8A16: dequantised to bf16 at the MFMA input, bf16 MFMA)"
 
     @property

@@ -36,6 +36,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.bf16_activations = 0 if bf16_activations else -1
     ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "fp8": _lib.FP8}[cfg.weight_dtype]
     ec.packed_rows = 0 if packed_rows is None else (1 if packed_rows else -1)
+    ec.fp8_activations = int(bool(getattr(cfg, "fp8_activations", False)) and cfg.weight_dtype == "fp8")
     return ec
 
 

@@ -92,10 +92,11 @@ def moe_expert_workspace_size(S, E, D, F):
 
 
 def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None,
-                   w1_scale=None, w2_scale=None, out=None):
+                   w1_scale=None, w2_scale=None, out=None, h_scale=None):
     """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue (gate, residual, LayerNorm).
     The expert weights pick the kernel family: fp32; bf16 (bf16 MFMA, fp32 accumulate); e4m3 with per-row scales
-    w1_scale [E,F] / w2_scale [E,D] (dequantised to bf16 at the MFMA input).  Biases are fp32 in every mode."""
+    w1_scale [E,F] / w2_scale [E,D] (dequantised to bf16 at the MFMA input; with h_scale: fp8 arithmetic, activations
+    quantised too -- m3_moe_expert_ffn_fp8a8).  Biases are fp32 in every mode."""
     lib = _lib.load()
     assert w1.dtype == w2.dtype and w1.is_contiguous() and w2.is_contiguous()
     S, D = x.shape
@@ -108,7 +109,12 @@ def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alp
     tail = (S, E, D, F, gate, _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(workspace),
             workspace.numel(), _stream())
     xi, gi = _f32(x), _i32(gate_idx.reshape(-1))
-    if w1.dtype == torch.float8_e4m3fn:
+    if w1.dtype == torch.float8_e4m3fn and h_scale is not None:
+        # fp8 arithmetic: activations quantised too (rows: per-row dynamic scale; H: the static scale h_scale)
+        assert w1_scale is not None and w2_scale is not None, "fp8 expert weights need their per-row scales"
+        check(lib.m3_moe_expert_ffn_fp8a8(xi, gi, _p(w1), _f32(w1_scale), _f32(b1), _p(w2), _f32(w2_scale), _f32(b2),
+                                          float(h_scale), *tail), "m3_moe_expert_ffn_fp8a8")
+    elif w1.dtype == torch.float8_e4m3fn:
         assert w1_scale is not None and w2_scale is not None, "fp8 expert weights need their per-row scales"
         check(lib.m3_moe_expert_ffn_fp8(xi, gi, _p(w1), _f32(w1_scale), _f32(b1), _p(w2), _f32(w2_scale), _f32(b2), *tail),
               "m3_moe_expert_ffn_fp8")

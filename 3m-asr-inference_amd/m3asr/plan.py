@@ -126,6 +126,11 @@ def _pack_block(sd, p, out, norm, moe, cfg):
                                                          sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"]))
         if (f + "router_bias") in sd:
             out[f + "router_bias"] = sd[f + "router_bias"]
+        if getattr(cfg, "fp8_activations", False) and cfg.weight_dtype == "fp8":
+            # static scale of the hidden activations for the fp8-arithmetic expert FFN: from the calibrator
+            # (m3asr/calibrate.py writes "...experts.h_scale" into the state dict), else the uncalibrated default
+            hs = sd.get(f + "experts.h_scale")
+            out[f + "experts.h_scale"] = (hs.reshape(1).float() if hs is not None else torch.tensor([DEFAULT_H_SCALE]))
         lo = cfg.ep_rank * cfg.num_experts if cfg.ep_world_size > 1 else 0
         for n in ("experts.w_1.weight", "experts.w_1.bias", "experts.w_2.weight", "experts.w_2.bias"):
             t = sd[f + n]
@@ -211,6 +216,12 @@ def is_gemm_weight(name):
 
 
 FP8_MAX = 448.0    # largest finite OCP e4m3 value
+
+
+# uncalibrated H scale of the fp8-arithmetic expert FFN: |H| up to 448 * 0.05 = 22.4 is representable (H = SiLU(z) of a
+# LayerNorm'd input through ~unit-gain weights stays below that); e4m3 is floating point, so a loose scale costs range, not
+# precision -- the calibrator (m3asr/calibrate.py) replaces it by 1.25 x the observed maximum / 448
+DEFAULT_H_SCALE = 0.05
 
 
 def quantize_fp8_rows(w, dims):

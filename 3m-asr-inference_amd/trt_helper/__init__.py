@@ -5,6 +5,7 @@ from . import trt
 from .builder_helper import init_trt_plugin, HelperConfig, BuilderHelper
 from .network_helper import NetworkHelper, PluginRegistry, PluginCreator
 from .infer_helper import InferHelper
+from m3asr.calibrate import AsrCalibrator
 
 __all__ = ["trt", "init_trt_plugin", "HelperConfig", "BuilderHelper", "NetworkHelper", "InferHelper",
-           "PluginRegistry", "PluginCreator"]
+           "PluginRegistry", "PluginCreator", "AsrCalibrator"]

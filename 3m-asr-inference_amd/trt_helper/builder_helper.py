@@ -70,10 +70,20 @@ class BuilderHelper:
         # the reference wires --fp16 / --int8 but never finished them (builder.py:39-49; fmoe asserts on HALF).
         # Here --fp16 (use_fp16 / plugin_data_type HALF) selects the 16-bit weight mode of the engine: bf16 storage and
         # bf16 MFMA with fp32 accumulation (bf16 is the 16-bit type of CDNA4); int8 / fp8 is not implemented.
-        if config.use_int8 or int(config.plugin_data_type) not in (0, 1):
-            raise RuntimeError("int8 / fp8 calibration is not implemented (fp32 and the 16-bit --fp16 mode are)")
+        # --int8 (use_int8 / plugin_data_type 2) is the reference's 8-bit slot (builder.py:39-49, builder_helper.py:109-123:
+        # "config.use_int8 is true, but calibrator is None!").  8-bit on CDNA4 is fp8: e4m3 expert weights and fp8
+        # ARITHMETIC in the grouped expert FFN of long batches, with the activation scales taken from the calibrator's
+        # batches (m3asr/calibrate.py).  use_fp8 without a calibrator = the weight-only form (no data needed).
+        if int(config.plugin_data_type) not in (0, 1, 2):
+            raise RuntimeError("plugin_data_type must be 0 (float), 1 (half) or 2 (8-bit)")
         self.weight_dtype = "bf16" if (config.use_fp16 or int(config.plugin_data_type) == 1) else "f32"
-        if getattr(config, "use_fp8", False):
+        self.fp8_activations = False
+        self.calibrator = calibrator
+        if config.use_int8 or int(config.plugin_data_type) == 2:
+            if calibrator is None:
+                raise RuntimeError("config.use_int8 is true, but calibrator is None!")
+            self.weight_dtype, self.fp8_activations = "fp8", True
+        elif getattr(config, "use_fp8", False):
             self.weight_dtype = "fp8"
         self.device = torch.device(device)
         self.profiles = {}
@@ -123,9 +133,22 @@ class BuilderHelper:
         nh = self.network_helper
         if not nh.outputs:
             raise RuntimeError("build_engine: no output marked")
-        if self.weight_dtype != self.model_cfg.weight_dtype:
-            import dataclasses
-            self.model_cfg = dataclasses.replace(self.model_cfg, weight_dtype=self.weight_dtype)
+        import dataclasses
+        if self.weight_dtype != self.model_cfg.weight_dtype or self.fp8_activations != self.model_cfg.fp8_activations:
+            self.model_cfg = dataclasses.replace(self.model_cfg, weight_dtype=self.weight_dtype,
+                                                 fp8_activations=self.fp8_activations)
+        if self.fp8_activations:
+            from m3asr.calibrate import calibrate_h_scales
+            cache = self.calibrator.read_calibration_cache() if hasattr(self.calibrator, "read_calibration_cache") else None
+            if cache and len(cache.get("h_scale", [])) == self.model_cfg.num_blocks:
+                for i, v in enumerate(cache["h_scale"]):
+                    self.model["blocks.%d.feed_forward.experts.h_scale" % i] = torch.tensor([float(v)])
+                self.logger.log(trt.Logger.INFO, "[Builder] activation scales read from the calibration cache")
+            else:
+                scales = calibrate_h_scales(self.model_cfg, self.model, iter(self.calibrator), device=str(self.device))
+                if hasattr(self.calibrator, "write_calibration_cache"):
+                    self.calibrator.write_calibration_cache({"h_scale": scales})
+                self.logger.log(trt.Logger.INFO, "[Builder] calibrated h_scale per MoE layer: min %.4f max %.4f" % (min(scales), max(scales)))
         packed = pack_weights(self.model, self.model_cfg)
         extra = getattr(self, "output_bias", None)            # e.g. -log prior (builder.py:83-88)
         add_front_back_end(packed, self.model_cfg, cmvn=getattr(self, "cmvn", None), output_bias=extra)

@@ -44,9 +44,13 @@ def build_trt(model, args, input_dim, plan_name, prior=None, profile=None):
         cfg.use_fp16, cfg.plugin_data_type = True, trt.DataType.HALF
     if args.fp8:
         cfg.use_fp8 = True                          # e4m3 expert weights + bf16 dense weights (W8A16), no calibration needed
+    calibrator = None
     if args.int8:
+        # the reference's 8-bit slot (builder.py:43-47 there: plugin_data_type, use_int8 and an AsrCalibrator over lists of
+        # .npy feature files, behind an `assert 0`): fp8 arithmetic with the activation scales calibrated on those files
         cfg.use_int8 = True
-    builder_helper = trt_helper.BuilderHelper(cfg, logger, None)
+        calibrator = trt_helper.AsrCalibrator(args.calib_feat_list, args.calib_feat_len_list, args.calib_cache, args.calib_batches)
+    builder_helper = trt_helper.BuilderHelper(cfg, logger, calibrator)
     nh = builder_helper.get_network_helper()
     feat = nh.addInput(name="feat", dtype=trt.float32, shape=(-1, -1, input_dim))
     feat_len = nh.addInput(name="feat_len", dtype=trt.int32, shape=(1, -1))
@@ -112,6 +116,10 @@ if __name__ == "__main__":
     p.add_argument("-f", "--fp16", action="store_true")
     p.add_argument("-i", "--int8", action="store_true")
     p.add_argument("--fp8", action="store_true", help="expert weights as fp8 e4m3 with per-row scales, dense weights bf16")
+    p.add_argument("--calib-feat-list", default="np_inputs/np_feat.list", help="--int8: text file, one .npy feature batch per line")
+    p.add_argument("--calib-feat-len-list", default="np_inputs/np_feat_len.list", help="--int8: matching .npy length files")
+    p.add_argument("--calib-cache", default="conformer.int8.cache", help="--int8: calibration cache (JSON of the scales)")
+    p.add_argument("--calib-batches", type=int, default=10)
     p.add_argument("-t", "--strict", action="store_true")
     p.add_argument("-w", "--workspace-size", default=1000, type=int)
     p.add_argument("-tcf", "--timing-cache-file", required=False)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 4
+#define M3ASR_ABI_VERSION 5
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -131,6 +131,18 @@ int m3_moe_expert_ffn_fp8(const float* x, const int32_t* gate_idx, const void* w
                           int idim, int hidden_units, const float* gate_value, const float* resid, float alpha,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* workspace,
                           size_t workspace_bytes, m3_stream stream);
+/* fp8 ARITHMETIC (A8W8; the path the reference's --int8 flag names, builder.py:39-49): e4m3 weights as above, the rows
+ * quantised to e4m3 with a per-row dynamic scale (amax / 448) while they are loaded, H quantised with the static per-layer
+ * scale h_scale (calibrated: amax of H x 1.25 / 448), products on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation.  Taken
+ * where the fused fp8 kernel applies (m3_moe_expert_ffn_fp8a8_active: idim 512, >= 4096 rows, >= 64 rows per expert);
+ * shorter inputs are weight-streaming bound and run the weight-only form of m3_moe_expert_ffn_fp8 (identical signature
+ * otherwise). */
+int m3_moe_expert_ffn_fp8a8(const float* x, const int32_t* gate_idx, const void* w1, const float* w1_scale,
+                            const float* b1, const void* w2, const float* w2_scale, const float* b2, float h_scale, int S,
+                            int num_expert, int idim, int hidden_units, const float* gate_value, const float* resid,
+                            float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y,
+                            void* workspace, size_t workspace_bytes, m3_stream stream);
+int m3_moe_expert_ffn_fp8a8_active(int S, int num_expert, int idim, int hidden_units);
 /* The tail of the MoE layer on rows that are already in scattered (expert-sorted) order, e.g. rows that came back
  * from the expert-parallel all-to-all:  out[s] = LayerNorm( resid[s] + alpha * gate_value[s] * rows[mapping[s]] )
  * (rows with mapping < 0 contribute 0; gate_value / resid / ln_* may be NULL).  = local_gather
@@ -321,6 +333,10 @@ typedef struct m3_engine_config {
                                   * debug taps / fused routing, -1 = never, 1 = also for B = 1).  The interface does not
                                   * change: logits come back as (B, T', V), zeros past each utterance's last frame; the
                                   * "x" / "xn" / "embed" buffers then hold packed rows ("row0" = first row per utterance) */
+  int32_t fp8_activations;       /* weight_dtype M3_FP8 only: 1 = fp8 ARITHMETIC in the grouped expert FFN where the fused
+                                  * fp8 kernel applies (long batches): rows quantised per row, H with the static per-layer
+                                  * scale "blocks.N.feed_forward.experts.h_scale" of the plan (calibrated); elsewhere the
+                                  * weight-only form runs */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

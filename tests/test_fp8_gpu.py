@@ -96,6 +96,60 @@ def test_fmoe_expert_fp8(S, E, D, Fh, mode):
     assert float((y.cpu() - y32.view(S, D)).abs().max()) < 1e-1 * float(y32.abs().max())
 
 
+def _q8(t):
+    """round-to-nearest-even to e4m3 after clamping to +-448 (what the kernel's v_med3 + v_cvt_pk_fp8_f32 do), in fp64"""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double()
+
+
+@pytest.mark.parametrize("S,E,D,Fh,mode", [(4096, 32, 512, 1024, "uniform"), (16384, 32, 512, 1024, "uniform"),
+                                           (6500, 8, 512, 1024, "with_dropped"), (9000, 64, 512, 1024, "uniform"),
+                                           (40000, 32, 512, 1024, "with_dropped"), (5000, 16, 512, 2048, "all_one")])
+def test_fmoe_expert_fp8_arithmetic(S, E, D, Fh, mode):
+    """fp8 ARITHMETIC (m3_moe_expert_ffn_fp8a8: e4m3 weights x e4m3 activations, v_mfma_f32_32x32x16_fp8_fp8) against an
+    fp64 evaluation of exactly the quantised computation it defines: rows quantised with the per-row scale amax / 448, H with
+    the static scale h_scale, exact products, then the scales and biases.  Elements of X / H that land on an e4m3 rounding
+    boundary may round the other way than in the fp64 evaluation (the kernel forms x * (448 / amax) and z in fp32): bound
+    3e-3 of the output scale.  And within e4m3 accuracy (3 mantissa bits on both operands) of the unquantised fp32 FFN."""
+    g, x, (w1, b1, w2, b2), (q1, s1, q2, s2) = _expert_case(S, E, D, Fh, mode)
+    assert ops._lib.load().m3_moe_expert_ffn_fp8a8_active(S, E, D, Fh) == 1
+    # static H scale as the calibrator would set it: amax of the (unquantised) hidden activations x 1.25 / 448
+    hmax = 0.0
+    for e in range(E):
+        rows = (g == e).nonzero().flatten()
+        if rows.numel():
+            hmax = max(hmax, float(F.silu(x[rows] @ w1[e].t() + b1[e]).abs().max()))
+    h_scale = hmax * 1.25 / 448.0
+    y = ops.moe_expert_ffn(dev(x), dev(g), dev(q1), dev(b1), dev(q2), dev(b2), w1_scale=dev(s1), w2_scale=dev(s2),
+                           h_scale=h_scale)
+    want = torch.zeros(S, D, dtype=torch.float64)
+    for e in range(E):
+        rows = (g == e).nonzero().flatten()
+        if rows.numel():
+            xr = x[rows]
+            amax = xr.abs().amax(1, keepdim=True).clamp_min(1e-30)
+            xq = _q8(xr * (448.0 / amax))                                  # fp32 product, as in the kernel
+            sx = (amax * (1.0 / 448.0)).double()
+            z = (xq @ q1[e].double().t()) * (s1[e].double() * sx) + b1[e].double()
+            hq = _q8(F.silu(z).float() * (1.0 / h_scale))
+            want[rows] = (hq @ q2[e].double().t()) * (s2[e].double() * h_scale) + b2[e].double()
+    scale = float(want.abs().max())
+    row_err = ((y.cpu().double() - want).abs().amax(1) / scale).numpy()
+    live = (g >= 0).numpy()
+    q50, q90, qmax = (float(np.quantile(row_err[live], q)) for q in (0.5, 0.9, 1.0))
+    print("fp8 arithmetic S=%d E=%d F=%d: row error vs the fp64 evaluation of the quantised computation, of the output scale: "
+          "median %.2e, 90 %% %.2e, max %.2e" % (S, E, Fh, q50, q90, qmax))
+    # most rows agree to fp32 summation noise; a row where ONE element of H sits on an e4m3 rounding boundary (the kernel's
+    # SiLU and the fp64 one differ by ~1e-6) moves by one e4m3 step of that element -- up to 32 h_scale for the largest
+    # activations (3 mantissa bits) times a W2 entry: percent-level for that row, ~1 row in 50
+    assert q50 < 2e-4 and q90 < 4e-3 and qmax < 4e-2, (q50, q90, qmax)
+    assert bool((y.cpu()[g < 0] == 0).all())
+    from oracle import encoder_ref as ref
+    y32, _, _ = ref.fmoe_expert(x.view(1, S, D), g.view(1, S, 1), w1, b1, w2, b2)
+    q_err = float((y.cpu() - y32.view(S, D)).abs().max()) / float(y32.abs().max())
+    print("   vs the unquantised fp32 expert FFN: %.3e" % q_err)
+    assert q_err < 8e-2, q_err
+
+
 FP8_REL = 2e-2      # weight-only e4m3 (3 mantissa bits): measured 0.9-1.0e-2 teacher-forced
 
 
@@ -162,3 +216,46 @@ def test_ep_world1_fp8_equals_engine():
     want = Engine.from_state_dict(cfg, w, packed_rows=False)(feat, fl).clone()
     ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False))
     assert torch.equal(ep.forward(feat, fl), want)
+
+
+def test_engine_fp8_arithmetic_long_batch_calibrated():
+    """EncoderConfig.fp8_activations: on a long batch the grouped expert FFN runs the fused fp8 kernel (e4m3 x e4m3 MFMA) with
+    the calibrated per-layer H scale; against the fp32 oracle teacher-forced to the engine's routing the error stays at
+    the e4m3 level (both operands 3 mantissa bits): <= 3e-2 of the largest logit; the weight-only engine is the reference
+    point.  Short inputs of the same engine take the weight-only form (nothing to gain from quantising 50 rows)."""
+    from m3asr.calibrate import calibrate_h_scales
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=1)
+    w = make_weights(cfg, seed=11)
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(200, 501, 64)
+    lengths[0] = 500
+    feat = torch.from_numpy(rng.random((64, 500, cfg.input_dim), dtype=np.float32))
+    fl = torch.from_numpy(lengths.astype(np.int32))
+    calib = [(torch.from_numpy(rng.random((8, 300, cfg.input_dim), dtype=np.float32)), torch.full((8,), 300, dtype=torch.int32))
+             for _ in range(2)]
+    scales = calibrate_h_scales(cfg, w, calib)
+    assert len(scales) == cfg.num_blocks and all(1e-4 < v < 1.0 for v in scales)
+    cfg8 = EncoderConfig(**{**cfg.__dict__, "weight_dtype": "fp8", "fp8_activations": True})
+    eng = Engine.from_state_dict(cfg8, w)
+    out = eng(feat.cuda(), fl.view(1, -1).cuda()).cpu()
+    kernels = {s_["name"]: s_["kernel"] for s_ in eng.stage_info()}
+    assert kernels["blocks.0.moe_local.expert"] == "expert_ffn_fused_fp8_kernel"
+    B, Tp = out.shape[0], out.shape[1]
+    forced = {"blocks.%d.gate_idx" % i: eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(B, Tp, 1).clone()
+              for i in range(cfg.num_blocks)}
+    want = encoder_forward(w, cfg, feat, fl, route_override=forced)
+    valid = torch.arange(Tp).view(1, -1) < sub_len(fl.long()).view(-1, 1)
+    err = float((out - want).abs()[valid].max()) / float(want.abs()[valid].max())
+    w8 = Engine.from_state_dict(EncoderConfig(**{**cfg.__dict__, "weight_dtype": "fp8"}), w)
+    out_w8 = w8(feat.cuda(), fl.view(1, -1).cuda()).cpu()
+    assert {s_["name"]: s_["kernel"] for s_ in w8.stage_info()}["blocks.0.moe_local.expert"] != "expert_ffn_fused_fp8_kernel"
+    err_w8 = float((out_w8 - want).abs()[valid].max()) / float(want.abs()[valid].max())
+    print("fp8 arithmetic engine (B=64, 2 blocks): max |err| / max |logit| = %.3e teacher-forced (weight-only engine, free-running "
+          "routing of its own, against the same reference: %.3e)" % (err, err_w8))
+    assert err < 3e-2, err
+    # short input, same engine: the weight-only expert kernel
+    f1 = torch.rand(1, 206, cfg.input_dim, generator=torch.Generator().manual_seed(1)).cuda()
+    l1 = torch.tensor([[206]], dtype=torch.int32).cuda()
+    y1 = eng(f1, l1).clone()
+    assert {s_["name"]: s_["kernel"] for s_ in eng.stage_info()}["blocks.0.moe_local.expert"] == "expert_ffn_w8_kernel"
+    assert torch.equal(y1, w8(f1, l1))

@@ -17,10 +17,20 @@ w1 = (torch.randn(E, F, D, generator=g) * D ** -0.5)
 w2 = (torch.randn(E, D, F, generator=g) * F ** -0.5)
 b1 = torch.randn(E, F, generator=g) * 0.1
 b2 = torch.randn(E, D, generator=g) * 0.1
-WDT = torch.float32 if os.environ.get("EXP_DTYPE", "bf16") == "f32" else torch.bfloat16
-w1h, w2h = w1.to(WDT).to(dev), w2.to(WDT).to(dev)
+DT = os.environ.get("EXP_DTYPE", "bf16")
+WDT = torch.float32 if DT == "f32" else torch.bfloat16
 b1d, b2d = b1.to(dev), b2.to(dev)
-fn = lambda: ops.moe_expert_ffn(x, gate, w1h, b1d, w2h, b2d)
+if DT in ("fp8", "fp8a8"):        # e4m3 weights + per-row scales; fp8a8: activations quantised too (fp8 MFMA)
+    from m3asr.plan import quantize_fp8_rows
+    q1, s1 = quantize_fp8_rows(w1, dims=(2,))
+    q2, s2 = quantize_fp8_rows(w2, dims=(2,))
+    q1d, s1d, q2d, s2d = q1.to(dev), s1.to(dev), q2.to(dev), s2.to(dev)
+    w1h, w2h = (q1.float() * s1.unsqueeze(-1)).to(WDT).to(dev), (q2.float() * s2.unsqueeze(-1)).to(WDT).to(dev)
+    hs = 0.05 if DT == "fp8a8" else None
+    fn = lambda: ops.moe_expert_ffn(x, gate, q1d, b1d, q2d, b2d, w1_scale=s1d, w2_scale=s2d, h_scale=hs)
+else:
+    w1h, w2h = w1.to(WDT).to(dev), w2.to(WDT).to(dev)
+    fn = lambda: ops.moe_expert_ffn(x, gate, w1h, b1d, w2h, b2d)
 y = fn()
 # reference on a sample of rows, fp32 math on the bf16-rounded weights
 idx = torch.arange(0, S, max(1, S // 256))
@@ -48,5 +58,5 @@ with torch.cuda.stream(st):
     e1.record(st)
     st.synchronize()
 us = e0.elapsed_time(e1) / 100 * 1e3
-print(json.dumps({"lib": os.environ.get("M3ASR_LIB", "in-tree"), "S": S, "dtype": str(WDT), "op_us": round(us, 2),
+print(json.dumps({"lib": os.environ.get("M3ASR_LIB", "in-tree"), "S": S, "dtype": DT, "op_us": round(us, 2),
                   "TFLOPs": round(4 * D * F * S / us / 1e6, 1), "rel_err": round(err, 5)}), flush=True)

@@ -17,7 +17,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // PIECE bytes per slot, RING slots, INSTR = PIECE / 1024 / 4 fills per wave per piece
 template <int PIECE, int RING, int FORM, bool SWZ>
 __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ w, size_t region_bytes, int share, int dephase,
-                                                   int bytes_per_wg, float* __restrict__ sink) {
+                                                   int bytes_per_wg, float* __restrict__ sink, int gap,
+                                                   unsigned long long* __restrict__ issue_cycles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IPW = PIECE / 1024 / 4;
   const int lane = threadIdx.x & 63;
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ w, s
     }
   };
   float acc = 0.f;
+  unsigned long long t_issue = 0;
 #pragma unroll
   for (int t = 0; t < RING - 1; ++t) issue(t);
   for (int t = 0; t < npieces; ++t) {
@@ -58,33 +60,46 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ w, s
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     if (t + RING - 1 < npieces) issue(t + RING - 1);
+    asm volatile("" ::: "memory");
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    t_issue += c1 - c0;
     acc += *reinterpret_cast<const float*>(smem + (t % RING) * PIECE + threadIdx.x * 16);
+    if (gap > 0) {                                       // a compute phase between bursts, as in the fused kernel
+      while (__builtin_amdgcn_s_memtime() - c1 < (unsigned long long)gap) __builtin_amdgcn_s_sleep(2);
+    }
   }
   if (acc == 123.456f) sink[0] = acc;
+  if (threadIdx.x == 0 && blockIdx.x == 17) issue_cycles[0] = t_issue;
 }
 
 template <int PIECE, int RING, int FORM, bool SWZ>
-static void run(const char* name, const char* w, size_t region_bytes, int nregions, int share, int dephase, float* sink) {
+static void run(const char* name, const char* w, size_t region_bytes, int nregions, int share, int dephase, float* sink, int gap = 0) {
+  static unsigned long long* d_ic = nullptr;
+  if (!d_ic) CHECK(hipMalloc(&d_ic, 8));
   const int nwg = nregions * share;
   const int bytes_per_wg = 2 << 20;
   CHECK(hipFuncSetAttribute((const void*)fill_kernel<PIECE, RING, FORM, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, PIECE * RING));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int it = 0; it < 3; ++it)
-    hipLaunchKernelGGL((fill_kernel<PIECE, RING, FORM, SWZ>), dim3(nwg), dim3(256), PIECE * RING, 0, w, region_bytes, share, dephase, bytes_per_wg, sink);
+    hipLaunchKernelGGL((fill_kernel<PIECE, RING, FORM, SWZ>), dim3(nwg), dim3(256), PIECE * RING, 0, w, region_bytes, share, dephase, bytes_per_wg, sink, gap, d_ic);
   CHECK(hipEventRecord(e0));
   const int iters = 10;
   for (int it = 0; it < iters; ++it)
-    hipLaunchKernelGGL((fill_kernel<PIECE, RING, FORM, SWZ>), dim3(nwg), dim3(256), PIECE * RING, 0, w, region_bytes, share, dephase, bytes_per_wg, sink);
+    hipLaunchKernelGGL((fill_kernel<PIECE, RING, FORM, SWZ>), dim3(nwg), dim3(256), PIECE * RING, 0, w, region_bytes, share, dephase, bytes_per_wg, sink, gap, d_ic);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / iters;
   const double rounds = (nwg + 255) / 256;
-  printf("%-44s wgs %4d share %2d dephase %d : %8.1f us  %6.1f GB/s per CU (%.2f TB/s chip)\n", name, nwg, share, dephase, us,
-         (double)bytes_per_wg * rounds / us / 1e3, (double)bytes_per_wg * nwg / us / 1e6);
+  unsigned long long ic = 0;
+  CHECK(hipMemcpy(&ic, d_ic, 8, hipMemcpyDeviceToHost));
+  const int n_issue = bytes_per_wg / 1024 / 4;
+  printf("%-30s wgs %4d share %2d dephase %d gap %5d : %8.1f us  %6.1f GB/s per CU (%.2f TB/s chip), %.0f cycles per fill issue\n", name, nwg,
+         share, dephase, gap, us, (double)bytes_per_wg * rounds / us / 1e3, (double)bytes_per_wg * nwg / us / 1e6, (double)ic / n_issue);
 }
 
 int main() {
@@ -111,5 +126,11 @@ int main() {
   // everything from L2: all 256 work-groups share ONE 2 MB region / 8 regions (one per XCD)
   run<16384, 8, 0, true>("16K x8 buffer swz", w, region, 1, 256, 1, sink);
   run<16384, 8, 0, true>("16K x8 buffer swz", w, region, 8, 32, 1, sink);
+  // bursts separated by a compute-like gap (cycles), shared regions as in the fused kernel
+  run<32768, 4, 0, true>("32K x4 buffer swz", w, region, 16, 16, 1, sink, 1000);
+  run<32768, 4, 0, true>("32K x4 buffer swz", w, region, 16, 16, 1, sink, 2200);
+  run<32768, 4, 0, true>("32K x4 buffer swz", w, region, 16, 16, 1, sink, 4400);
+  run<16384, 8, 0, true>("16K x8 buffer swz", w, region, 16, 16, 1, sink, 1100);
+  run<32768, 4, 0, true>("32K x4 buffer swz (private)", w, region, 256, 1, 0, sink, 2200);
   return 0;
 }
