@@ -53,6 +53,23 @@ constexpr int kD = 512;
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
 }
+// The same LDS-DMA fill as inline assembly.  hipcc's waitcnt insertion treats a buffer_load ... lds it can see as a pending
+// write to ALL of LDS and puts s_waitcnt vmcnt(0) in front of every later ds_write / ds_read of the loop -- which would also
+// drain the register-staged weight loads each time.  Hidden in asm, the fill is invisible to that pass: hipcc's own vmcnt
+// waits then under-count the operations in flight (they wait for a little more than needed, never less) and the waits for the
+// fills themselves are written by hand (wait_vmcnt below).
+__device__ __forceinline__ void dma16_hidden(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+// Y leaves through stores hipcc does not see either: with loads AND stores pending in its model (gfx9 counts both in vmcnt
+// and they may complete out of order), every later wait for a load becomes s_waitcnt vmcnt(0) until a vmcnt(0) is executed
+// on all paths -- in the persistent tile loop that turned each wait for a staged weight KB into a full drain.  Nothing ever
+// waits for these stores (the end of the kernel does); an unseen store in flight only makes a counted wait for an older load
+// conservative, because loads return in order among themselves.
+__device__ __forceinline__ void store16_nt_hidden(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -77,21 +94,72 @@ __device__ __forceinline__ int pi8_row(int rho) {
 
 }  // namespace
 
+struct TileRef {
+  int e, tt, fs;
+};
+// item -> (expert, token tile of the expert, F part), from the histogram alone (one wave scan per 64 experts); uniform
+__device__ __forceinline__ TileRef find_tile(const int32_t* __restrict__ acc_hist, int E, int item, int fsplit, int lane) {
+  const int tile = item / fsplit;
+  int e = -1, tt = 0, base = 0;
+  for (int e0 = 0; e0 < E; e0 += 64) {
+    const int ee = e0 + lane;
+    const int cnt = ee < E ? acc_hist[ee + 1] - acc_hist[ee] : 0;
+    const int nt = (cnt + kTok - 1) / kTok;
+    int incl = nt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    const int excl = base + incl - nt;
+    const unsigned long long m = __ballot(tile >= excl && tile < excl + nt);
+    if (m) {
+      const int src = __ffsll((long long)m) - 1;
+      e = e0 + src;
+      tt = tile - __shfl(excl, src, 64);
+      break;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+  return TileRef{__builtin_amdgcn_readfirstlane(e), __builtin_amdgcn_readfirstlane(tt), item - tile * fsplit};
+}
+
+// LDS map (bytes): [0, 64 K) two 32-KB weight slots (slot 1 doubles as the Y staging area between two tiles) | [64 K, 72 K) b1,
+// s1 of the current tile's F range (<= 1024 floats each) | [72 K, 76 K) s2 * h_scale of the current / next tile's expert
+// | [76 K, 142 K) four wave-private X images [32 rows][528 B] (e4m3) | [142 K, 158 K) four wave-private raw rows x 2 (the
+// next tile's X arriving by LDS-DMA)
+constexpr int kOffBias = kRing * kPiece;
+constexpr int kOffS2 = kOffBias + 8192;
+constexpr int kOffImg = kOffS2 + 4096;
+constexpr int kImgRow = 528;
+constexpr int kOffRaw = kOffImg + 4 * 32 * kImgRow;
+constexpr int kLdsBytes = kOffRaw + 4 * 4096;
+
 template <int FSPLIT>
 __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const float* __restrict__ x, int ldx, const int32_t* __restrict__ pos, const int32_t* __restrict__ acc_hist, int S, int E,
     int F, const unsigned char* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ b1,
     const unsigned char* __restrict__ w2, const float* __restrict__ s2, int w2_row_stride, int w2_slice_stride, float h_scale,
-    float* __restrict__ ybuf, int nblk) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // two 32-KB slots | b1 | s1 of this work-group's F range
+    float* __restrict__ ybuf) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
+  // The kernel runs at the register limit (256 accumulator + 256 other registers, one wave per SIMD).  Per-lane address
+  // constants that live across the whole tile loop get spilled by hipcc -- and a scratch re-load inside the loop costs an
+  // s_waitcnt vmcnt(0), i.e. a drain of the weight loads in flight.  So the hot loop RECOMPUTES them from the lane id at
+  // every use (a handful of VALU operations in the MFMAs' shadow); the opaque copy keeps hipcc from hoisting them back out.
+  auto olane = [&]() {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
 
-  // ---- work-group -> (token tile, F part).  The number of real tiles T is only known on the device (it depends on the
-  //      routing): every work-group sums it from the histogram, then XCD x (= blockIdx % 8: work-groups b and b + 8 share an
-  //      XCD and its L2) takes the consecutive items [x * per, (x + 1) * per), per = ceil(T * FSPLIT / 8) -- the tiles of one
-  //      expert stay on one XCD and all XCDs get the same number of tiles; the surplus work-groups of the worst-case grid exit
+  // ---- PERSISTENT work-groups, one per CU.  The number of real tiles T is only known on the device (it depends on the
+  //      routing): every work-group sums it from the histogram; XCD x (= blockIdx % 8: work-groups b and b + 8 share an XCD
+  //      and its L2) owns the consecutive items [x * per, (x + 1) * per), per = ceil(T * FSPLIT / 8) -- the tiles of one
+  //      expert stay on one XCD and all XCDs get the same number of tiles -- and its work-groups walk them with stride
+  //      gridDim / 8, so the tiles in flight on an XCD at any time are neighbours (same experts) ----
   int total_tiles = 0;
   for (int e0 = 0; e0 < E; e0 += 64) {
     const int ee = e0 + lane;
@@ -100,60 +168,67 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     for (int d = 32; d >= 1; d >>= 1) nt += __shfl_xor(nt, d, 64);
     total_tiles += nt;
   }
-  const int items = total_tiles * FSPLIT;
+  const int items = __builtin_amdgcn_readfirstlane(total_tiles) * FSPLIT;
   const int per = (items + 7) >> 3;
-  const int slot_in_xcd = blockIdx.x >> 3;
-  const int logical = (blockIdx.x & 7) * per + slot_in_xcd;
-  if (slot_in_xcd >= per || logical >= items) return;  // (uniform over the work-group)
-  const int tile = logical / FSPLIT, fs = logical - tile * FSPLIT;
-  int e = -1, tt = 0;
-  {
-    int base = 0;
-    for (int e0 = 0; e0 < E; e0 += 64) {
-      const int ee = e0 + lane;
-      const int cnt = ee < E ? acc_hist[ee + 1] - acc_hist[ee] : 0;
-      const int nt = (cnt + kTok - 1) / kTok;
-      int incl = nt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += v;
-      }
-      const int excl = base + incl - nt;
-      const unsigned long long m = __ballot(tile >= excl && tile < excl + nt);
-      if (m) {
-        const int src = __ffsll((long long)m) - 1;
-        e = e0 + src;
-        tt = tile - __shfl(excl, src, 64);
-        break;
-      }
-      base += __shfl(incl, 63, 64);
-    }
-  }
-  if (e < 0) return;
+  const int stride = gridDim.x >> 3;
+  const int item_end = min(((int)(blockIdx.x & 7) + 1) * per, items);
+  int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (item >= item_end) return;                        // (uniform over the work-group)
   M3_DIAG(const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();)
-  e = __builtin_amdgcn_readfirstlane(e);               // provably uniform: descriptors / piece offsets stay in SGPRs
-  tt = __builtin_amdgcn_readfirstlane(tt);
-  const int row_begin = acc_hist[e], row_end = acc_hist[e + 1];
-  const int nsl = F / (64 * FSPLIT);                   // 64-wide slices of F this work-group contracts (even)
-  const int sl0 = fs * nsl;
-  const int phase0 = (tt * 5) % nsl;                   // de-phased walk over the slices (see moe_expert_fused_bf16.hip)
+
+  const int nsl = F / (64 * FSPLIT);                   // 64-wide slices of F a work item contracts
+  const int np = 2 * nsl;                              // pieces (= steps) per work item
+  float* b1_lds = reinterpret_cast<float*>(smem + kOffBias);
+  float* s1_lds = b1_lds + 1024;
+  float* s2h_lds = reinterpret_cast<float*>(smem + kOffS2);        // [2][512]: parity of the work-group's tile counter
+  char* img = smem + kOffImg + wv * (32 * kImgRow);
+  char* rawb = smem + kOffRaw + wv * 4096;
+
+  // ---- the current work item (everything below is wave-uniform and lives in SGPRs) ----
+  TileRef cur = find_tile(acc_hist, E, item, FSPLIT, lane);
+  if (cur.e < 0) return;
+  int row_end = acc_hist[cur.e + 1];
+  int tile_row0 = acc_hist[cur.e] + cur.tt * kTok + wv * 32;
+  int sl0 = cur.fs * nsl;
+  int phase0 = (cur.tt * 5) % nsl;                     // de-phased walk over the slices (see moe_expert_fused_bf16.hip)
+  const unsigned char* w1e = w1 + (size_t)cur.e * F * kD;
+  const unsigned char* w2e = w2 + (size_t)cur.e * F * kD;
   auto abs_slice = [&](int rel) { const int v = rel + phase0; return sl0 + (v >= nsl ? v - nsl : v); };
 
-  float* b1_lds = reinterpret_cast<float*>(smem + kRing * kPiece);
-  float* s1_lds = b1_lds + nsl * 64;
-
-  // ---- X: the 32 rows of this wave, quantised with each row's own scale, through a wave-private LDS image.
-  //      Rows are gathered through pos and read fully coalesced (two 1-KB instructions per row, lane = 16 bytes of the row),
-  //      amax by a wave reduction, e4m3 bytes to LDS (rows padded to 528 B: conflict-free 16-B column reads); then lane
-  //      (token r, half h) reads its fragments: k-step 2 m + s' holds x[32 m + 16 h + 8 s' + j], i.e. the 16 bytes at
-  //      32 m + 16 h of the row are the operands of two k-steps ----
+  // ---- X: 32 rows per wave, quantised with each row's own scale, through the wave-private LDS image: rows are gathered
+  //      through pos and read fully coalesced (two 1-KB instructions per row, lane = 16 bytes of the row), amax by a wave
+  //      reduction, e4m3 bytes to LDS (rows padded to 528 B: conflict-free 16-B column reads); then lane (token r, half h)
+  //      reads its fragments: k-step 2 m + s' holds x[32 m + 16 h + 8 s' + j], i.e. the 16 bytes at 32 m + 16 h of the row
+  //      are the operands of two k-steps ----
   long xq[kD / 16];
-  float sx = 1.f;
+  float sx = 1.f, sx_n = 1.f;
+  auto quant_row = [&](const f32x4& v0, const f32x4& v1, int i, float& sxv) {
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+    amax = fmaxf(wave_max(amax), 1e-30f);
+    const float inv = 448.f / amax;
+    if (r == i) sxv = amax * (1.f / 448.f);
+    int q0 = 0, q1 = 0;
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[0] * inv), clamp448(v0[1] * inv), q0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[2] * inv), clamp448(v0[3] * inv), q0, true);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[0] * inv), clamp448(v1[1] * inv), q1, false);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[2] * inv), clamp448(v1[3] * inv), q1, true);
+    *reinterpret_cast<int*>(img + i * kImgRow + 4 * lane) = q0;
+    *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * lane) = q1;
+  };
+  // (the image is private to this wave: LDS operations of one wave complete in order, no barrier needed)
+  auto read_xq = [&]() {
+    int off = r * kImgRow + 16 * h;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int m = 0; m < kD / 32; ++m) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(img + off + 32 * m);
+      xq[2 * m] = (long)(((unsigned long long)t[1] << 32) | t[0]);
+      xq[2 * m + 1] = (long)(((unsigned long long)t[3] << 32) | t[2]);
+    }
+  };
   {
-    constexpr int kXs = 528;
-    char* xs = smem + wv * (32 * kXs);
-    const int tile_row0 = row_begin + tt * kTok + wv * 32;
     const int my_src = pos[min(tile_row0 + r, row_end - 1)];          // source row of token r (lanes r and r + 32 agree)
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {                                    // 8 rows per batch: 16 loads in flight per lane
@@ -165,87 +240,108 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
         v[i][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 256));
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float amax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v[i][0][j]), fabsf(v[i][1][j])));
-        amax = fmaxf(wave_max(amax), 1e-30f);
-        const float inv = 448.f / amax;
-        if (r == 8 * g8 + i) sx = amax * (1.f / 448.f);
-        int q0 = 0, q1 = 0;
-        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[i][0][0] * inv), clamp448(v[i][0][1] * inv), q0, false);
-        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[i][0][2] * inv), clamp448(v[i][0][3] * inv), q0, true);
-        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[i][1][0] * inv), clamp448(v[i][1][1] * inv), q1, false);
-        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[i][1][2] * inv), clamp448(v[i][1][3] * inv), q1, true);
-        *reinterpret_cast<int*>(xs + (8 * g8 + i) * kXs + 4 * lane) = q0;
-        *reinterpret_cast<int*>(xs + (8 * g8 + i) * kXs + 256 + 4 * lane) = q1;
-      }
+      for (int i = 0; i < 8; ++i) quant_row(v[i][0], v[i][1], 8 * g8 + i, sx);
     }
-    // (the image is private to this wave: LDS operations of one wave complete in order, no barrier needed)
-#pragma unroll
-    for (int m = 0; m < kD / 32; ++m) {
-      const u32x4 t = *reinterpret_cast<const u32x4*>(xs + r * kXs + 32 * m + 16 * h);
-      xq[2 * m] = (long)(((unsigned long long)t[1] << 32) | t[0]);
-      xq[2 * m + 1] = (long)(((unsigned long long)t[3] << 32) | t[2]);
-    }
+    read_xq();
   }
-  __syncthreads();                                     // every wave is done with its X image: the slots may be filled
-  for (int i = threadIdx.x * 4; i < nsl * 64; i += 1024) {
-    *reinterpret_cast<f32x4*>(b1_lds + i) = ldg4(b1 + (size_t)e * F + sl0 * 64 + i);
-    *reinterpret_cast<f32x4*>(s1_lds + i) = ldg4(s1 + (size_t)e * F + sl0 * 64 + i);
+  if (threadIdx.x * 4 < nsl * 64) {
+    *reinterpret_cast<f32x4*>(b1_lds + threadIdx.x * 4) = ldg4(b1 + (size_t)cur.e * F + sl0 * 64 + threadIdx.x * 4);
+    *reinterpret_cast<f32x4*>(s1_lds + threadIdx.x * 4) = ldg4(s1 + (size_t)cur.e * F + sl0 * 64 + threadIdx.x * 4);
   }
+  s2h_lds[threadIdx.x] = s2[(size_t)cur.e * kD + threadIdx.x] * h_scale;
+  s2h_lds[threadIdx.x + 256] = s2[(size_t)cur.e * kD + threadIdx.x + 256] * h_scale;
+  int par = 0;
+
+  // ---- the NEXT tile's X arrives under this tile's MFMAs: two rows per step by LDS-DMA into the raw rows (no registers
+  //      held across the latency; 8 KB per CU in flight, below the LDS-DMA limit), quantised one step later ----
+  const unsigned long long xaddr = (unsigned long long)x;
+  const u32x4 rsx = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr),
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)((xaddr >> 32) & 0xffffu)),
+                     ((unsigned)(S - 1) * (unsigned)ldx + kD) * 4u, 0x00020000u};
+  const unsigned raw_lds = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)rawb);
+  int my_src_n = 0;
+  auto x_issue = [&](int i) {                           // row i of the next tile -> raw row i & 1
+    const unsigned soff = (unsigned)__builtin_amdgcn_readlane(my_src_n, i) * (unsigned)ldx * 4u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of the raw row's previous occupant have returned
+    const unsigned dst = raw_lds + (unsigned)(i & 1) * 2048u;
+    const unsigned voff = (unsigned)olane() * 16u;
+    dma16_hidden(rsx, voff, soff, dst);                   // (asm volatile + memory clobber: no load is moved across the
+    dma16_hidden(rsx, voff + 1024u, soff, dst + 1024u);   // fills; the counted waits rely on the issue order)
+  };
+  auto x_quant = [&](int i) {                           // (after the wait for row i's two fills)
+    // one 16-B piece of the row in registers at a time (the row is read three times from LDS instead of held in 8 VGPRs)
+    const int l = olane();
+    const char* src = rawb + (i & 1) * 2048 + l * 16;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    __builtin_amdgcn_sched_barrier(0);
+    v = *reinterpret_cast<const f32x4*>(src + 1024);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    amax = fmaxf(wave_max(amax), 1e-30f);
+    const float inv = 448.f / amax;
+    if ((l & 31) == i) sx_n = amax * (1.f / 448.f);
+    int q = 0;
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), q, false);
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), q, true);
+    *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * l) = q;
+    __builtin_amdgcn_sched_barrier(0);
+    v = *reinterpret_cast<const f32x4*>(src);
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), q, false);
+    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), q, true);
+    *reinterpret_cast<int*>(img + i * kImgRow + 4 * l) = q;
+  };
 
   // ---- weight staging through registers: wave wv brings KB 8 wv .. 8 wv + 7 of every 32-KB piece, natural (fully
   //      coalesced) source order; the row permutation pi8 and the bank swizzles are applied to the LDS DESTINATION ----
-  // W1 piece = 64 rows x 512 B: instruction ii covers rows f = 16 wv + 2 ii + (lane >> 5) (32 lanes x 16 B each); row f of
-  //   a block goes to LDS row rho = pi8^-1(f): f = [h' s a b1 b0] -> rho = [s a h' b1 b0]; 16-B chunk c = lane & 31 goes to
-  //   physical chunk (c & 16) | ((c ^ rho) & 15)
+  // W1 piece = 64 rows x 512 B.  LDS row rho of a piece holds the row f = 32 (rho >> 5) + pi8(rho & 31) of the slice; 16-B
+  //   chunk c of a row sits at physical chunk (c & 16) | ((c ^ rho) & 15).  Instruction ii of wave wv covers four HALF rows
+  //   (16 lanes x 16 B = 256 B each): rho = 16 (ii >> 1) + 4 wv + (lane >> 4), half ii & 1 -- the low four bits of rho (the
+  //   XOR key) and the row-dependent part of f then depend on the lane only, so source and destination are ONE per-lane
+  //   base each plus immediates (no per-instruction address registers)
   // W2 piece = 512 rows x 64 B: instruction ii covers rows 128 wv + 16 ii + (lane >> 2); chunk c = lane & 3 goes to physical
   //   chunk c ^ ((row >> 2) & 3) (independent of ii)
-  const unsigned char* w1e = w1 + (size_t)e * F * kD;
-  const unsigned char* w2e = w2 + (size_t)e * F * kD;
-  const unsigned src1_lane = (unsigned)(wv * 8192 + lane * 16);                       // + ii * 1024 + slice * 32768
-  const unsigned src2_lane = (unsigned)((128 * wv + (lane >> 2)) * w2_row_stride + (lane & 3) * 16);   // + ii * 16 rows + slice
-  const int hb = lane >> 5, c1 = lane & 31;
-  const int x1 = c1 ^ (4 * (wv & 1) + hb);                                            // (c ^ rho) low bits, ii part XORed in below
-  const unsigned dst2_lane = (unsigned)((128 * wv + (lane >> 2)) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
   u32x4 stg[8];                                        // the piece in flight (this wave's 8 KB)
   // one KB of the stream: ds_write the KB of piece t + 1 that arrived a step ago, then re-use its registers for the same KB
   // of piece t + 2.  A step spreads its 8 services between its MFMA batches: a wave that issues 8 loads back to back waits
   // ~160 cycles per load for the CU's load path (in-kernel stamps), one load per 8 MFMAs issues into an idle path.
-  auto load_kb = [&](int sl, int q, int ii) {
-    if (q == 0) stg[ii] = *reinterpret_cast<const u32x4*>(w1e + (size_t)sl * 32768 + src1_lane + ii * 1024);
-    else stg[ii] = *reinterpret_cast<const u32x4*>(w2e + (size_t)sl * w2_slice_stride + src2_lane + (size_t)ii * 16 * w2_row_stride);
+  auto load_kb = [&](const unsigned char* wa, const unsigned char* wb, int sl, int q, int ii) {
+    const int l = olane();
+    if (q == 0) {
+      const unsigned src1_lane = (unsigned)((16 * (wv & 1) + 4 * (wv >> 1) + (l >> 4)) * 512 + (l & 15) * 16);
+      stg[ii] = *reinterpret_cast<const u32x4*>(wa + (size_t)sl * 32768 + src1_lane + ((ii & 1) * 256 + ((ii >> 1) & 1) * 4096 + (ii >> 2) * 16384));
+    } else {
+      const unsigned src2_lane = (unsigned)((128 * wv + (l >> 2)) * w2_row_stride + (l & 3) * 16);   // + ii * 16 rows + slice
+      stg[ii] = *reinterpret_cast<const u32x4*>(wb + (size_t)sl * w2_slice_stride + src2_lane + (size_t)ii * 16 * w2_row_stride);
+    }
   };
   auto store_kb = [&](int q, int slot_i, int ii) {
     char* dst = smem + slot_i * kPiece;
+    const int l = olane();
     if (q == 0) {
-      const int rho = 32 * (wv >> 1) + 16 * (ii >> 2) + 8 * ((ii >> 1) & 1) + 4 * (wv & 1) + 2 * (ii & 1) + hb;
-      const int p = (c1 & 16) | ((x1 ^ (8 * ((ii >> 1) & 1) + 2 * (ii & 1))) & 15);
-      *reinterpret_cast<u32x4*>(dst + rho * 512 + p * 16) = stg[ii];
+      const int rho_l = 4 * wv + (l >> 4);
+      const unsigned dst1_lane = (unsigned)(rho_l * 512 + (((l & 15) ^ rho_l) << 4));
+      *reinterpret_cast<u32x4*>(dst + dst1_lane + (ii >> 1) * 8192 + (ii & 1) * 256) = stg[ii];
     } else {
+      const unsigned dst2_lane = (unsigned)((128 * wv + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4));
       *reinterpret_cast<u32x4*>(dst + dst2_lane + ii * 1024) = stg[ii];
     }
   };
 
-  const int rd1 = (r << 9) | ((h ^ (r & 15)) << 4);            // W1 block fb, step pair m: byte fb * 16384 + (rd1 ^ (m << 5))
-  const int rd2 = (r << 6) | ((h ^ ((r >> 2) & 3)) << 4);      // W2 block db, step pair m: byte db * 2048 + (rd2 ^ (m << 5))
+  // fragment read addresses: W1 block fb, step pair m: byte fb * 16384 + (rd1 ^ (m << 5)), rd1 = (r << 9) | ((h ^ (r & 15)) << 4)
+  //                          W2 block db, step pair m: byte db * 2048 + (rd2 ^ (m << 5)), rd2 = (r << 6) | ((h ^ ((r >> 2) & 3)) << 4)
 
   f32x16 accy[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) accy[i][j] = 0.f;
 
-  // pieces are numbered t = 2 * slice + q (q = 0: W1 rows, 1: W2 columns of the slice) and live in LDS slot t & 1
+  // pieces are numbered t = 2 * slice + q (q = 0: W1 rows, 1: W2 columns of the slice) and live in LDS slot t & 1; the
+  // stream runs on across tiles (np is even): pieces np, np + 1 of a tile are pieces 0, 1 of the work-group's next tile
 #pragma unroll
-  for (int ii = 0; ii < 8; ++ii) load_kb(abs_slice(0), 0, ii);
+  for (int ii = 0; ii < 8; ++ii) load_kb(w1e, w2e, abs_slice(0), 0, ii);
 #pragma unroll
   for (int ii = 0; ii < 8; ++ii) {
     store_kb(0, 0, ii);                                // piece 0 -> slot 0 (waits for its loads)
-    load_kb(abs_slice(0), 1, ii);                      // piece 1 in flight
+    load_kb(w1e, w2e, abs_slice(0), 1, ii);            // piece 1 in flight
   }
-  __syncthreads();                                     // b1 / s1 and piece 0 in LDS
 
   const float inv_h = 1.f / h_scale;
   long hq[2][2];                                       // Hq fragments of the current slice: [f block][k-step of the block]
@@ -253,42 +349,47 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   auto lo64 = [](const u32x4& a) { return (long)(((unsigned long long)a[1] << 32) | a[0]); };
   auto hi64 = [](const u32x4& a) { return (long)(((unsigned long long)a[3] << 32) | a[2]); };
   // SiLU + quantisation of a finished 32 x 32 block of z, a quarter (registers 4 q4 .. 4 q4 + 3 = f 32 fb + 16 h + 4 q4 ..)
-  // at a time: the quarters are issued between the MFMA batches of the NEXT block, so the VALU work runs in the MFMAs' shadow
-  float hv[16];
+  // at a time: the quarters are issued between the MFMA batches of the NEXT block, so the VALU work runs in the MFMAs' shadow;
+  // two quarters make the 8 bytes of one k-step of GEMM-2's B operand
+  float hv[8];
   auto silu_quarter = [&](const f32x16& acc, int sl_rel, int fb, int q4) {
-    const int fo = sl_rel * 64 + fb * 32 + 16 * h + 4 * q4;
+    const int fo = sl_rel * 64 + fb * 32 + 16 * (olane() >> 5) + 4 * q4;
     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + fo);
     const f32x4 ss = *reinterpret_cast<const f32x4*>(s1_lds + fo);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float z = acc[4 * q4 + j] * (ss[j] * sx) + bb[j];
-      hv[4 * q4 + j] = z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
+      hv[4 * (q4 & 1) + j] = z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
     }
+    if (q4 & 1) hq[fb][q4 >> 1] = q8(hv, inv_h);
   };
   f32x16 acc_a, acc_b;                                 // z blocks fb = 0 / 1 of the current slice
-  // fragment reads run one batch of 4 (16 VGPRs, 8 k-steps) ahead of the MFMAs that consume them
+  // fragment reads run two batches of 2 (8 VGPRs each, 4 k-steps) ahead of the MFMAs that consume them (ring of three)
   auto chain1 = [&](const char* blk, f32x16& acc, auto&& between) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    int rb = rd1;
-    asm volatile("" : "+v"(rb));
-    u32x4 a[2][4];
+    asm volatile("" : "+v"(acc));                       // z blocks live in arch VGPRs (SiLU reads them), the output tile in AGPRs
+    const int l = olane();
+    const int rb = ((l & 31) << 9) | (((l >> 5) ^ (l & 15)) << 4);
+    u32x4 a[3][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[0][j] = *reinterpret_cast<const u32x4*>(blk + (rb ^ (j << 5)));
+    for (int j = 0; j < 4; ++j) a[j >> 1][j & 1] = *reinterpret_cast<const u32x4*>(blk + (rb ^ (j << 5)));
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (b < 3) {
+    for (int bb = 0; bb < 8; ++bb) {
+      if (bb + 2 < 8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[(b + 1) & 1][j] = *reinterpret_cast<const u32x4*>(blk + (rb ^ ((4 * b + 4 + j) << 5)));
+        for (int j = 0; j < 2; ++j)
+          a[(bb + 2) % 3][j] = *reinterpret_cast<const u32x4*>(blk + (rb ^ ((2 * bb + 4 + j) << 5)));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = 4 * b + j;
-        acc = mfma8(lo64(a[b & 1][j]), xq[2 * m], acc);
-        acc = mfma8(hi64(a[b & 1][j]), xq[2 * m + 1], acc);
+      for (int j = 0; j < 2; ++j) {
+        const int m = 2 * bb + j;
+        acc = mfma8(lo64(a[bb % 3][j]), xq[2 * m], acc);
+        acc = mfma8(hi64(a[bb % 3][j]), xq[2 * m + 1], acc);
       }
-      between(b);
+      if (bb & 1) between(bb >> 1);
     }
+    asm volatile("" : "+v"(acc));
   };
   // step q = 0 of a slice: z block 0, then z block 1 with SiLU(block 0) in its shadow; SiLU(block 1) runs in GEMM-2's shadow
   auto gemm1 = [&](const char* slot, int sl_rel, auto&& service) {
@@ -297,106 +398,185 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
       silu_quarter(acc_a, sl_rel, 0, b);
       service(4 + b);
     });
-    hq[0][0] = q8(hv, inv_h);
-    hq[0][1] = q8(hv + 8, inv_h);
   };
   // step q = 1: pass A multiplies the f block 0 half of W2 (k-steps 0, 1) into all 16 output blocks while SiLU(block 1)
   // is computed, pass B the f block 1 half
   auto gemm2 = [&](const char* slot, int sl_rel, auto&& service) {
-    int rb = rd2;
-    asm volatile("" : "+v"(rb));
+    const int l = olane();
+    const int rb = ((l & 31) << 6) | (((l >> 5) ^ ((l >> 2) & 3)) << 4);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      u32x4 a[2][4];                                    // a batch = four output blocks
+      u32x4 a[3][2];                                    // a batch = two output blocks
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[0][k] = *reinterpret_cast<const u32x4*>(slot + k * 2048 + (rb ^ (m << 5)));
+      for (int k = 0; k < 4; ++k) a[k >> 1][k & 1] = *reinterpret_cast<const u32x4*>(slot + k * 2048 + (rb ^ (m << 5)));
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b < 3) {
+      for (int bb = 0; bb < 8; ++bb) {
+        if (bb + 2 < 8) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            a[(b + 1) & 1][k] = *reinterpret_cast<const u32x4*>(slot + (4 * b + 4 + k) * 2048 + (rb ^ (m << 5)));
+          for (int k = 0; k < 2; ++k)
+            a[(bb + 2) % 3][k] = *reinterpret_cast<const u32x4*>(slot + (2 * bb + 4 + k) * 2048 + (rb ^ (m << 5)));
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int db = 4 * b + k;
-          accy[db] = mfma8(lo64(a[b & 1][k]), hq[m][0], accy[db]);
-          accy[db] = mfma8(hi64(a[b & 1][k]), hq[m][1], accy[db]);
+        for (int k = 0; k < 2; ++k) {
+          const int db = 2 * bb + k;
+          accy[db] = mfma8(lo64(a[bb % 3][k]), hq[m][0], accy[db]);
+          accy[db] = mfma8(hi64(a[bb % 3][k]), hq[m][1], accy[db]);
         }
-        if (m == 0) silu_quarter(acc_b, sl_rel, 1, b);
-        service(4 * m + b);
-      }
-      if (m == 0) {
-        hq[1][0] = q8(hv, inv_h);
-        hq[1][1] = q8(hv + 8, inv_h);
+        if (bb & 1) {
+          if (m == 0) silu_quarter(acc_b, sl_rel, 1, bb >> 1);
+          service(4 * m + (bb >> 1));
+        }
       }
     }
   };
 
-  M3_DIAG(unsigned long long dg[5] = {0, 0, 0, 0, 0}; const unsigned long long t_begin = __builtin_amdgcn_s_memtime();)
-  // step t: barrier (every wave is done reading slot (t + 1) & 1, piece t is visible) -> MFMAs on piece t, and between the
-  // MFMA batches, KB by KB: ds_write piece t + 1 (arrived during step t - 1) into the other slot, load piece t + 2
-  const int np = 2 * nsl;
-  for (int sl = 0; sl < nsl; ++sl) {
+  M3_DIAG(unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; dg[6] = __builtin_amdgcn_s_memtime() - t_k0;)
+  for (;;) {
+    // ---- the work-group's next item (if any): its weights follow this tile's in the piece stream, its X is prefetched ----
+    const int item_n = item + stride;
+    const bool has_next = item_n < item_end;
+    TileRef nxt = cur;
+    if (has_next) nxt = find_tile(acc_hist, E, item_n, FSPLIT, lane);
+    const int row_end_n = acc_hist[nxt.e + 1];
+    const int tile_row0_n = acc_hist[nxt.e] + nxt.tt * kTok + wv * 32;
+    const int sl0_n = nxt.fs * nsl, phase0_n = (nxt.tt * 5) % nsl;
+    const unsigned char* w1n = w1 + (size_t)nxt.e * F * kD;
+    const unsigned char* w2n = w2 + (size_t)nxt.e * F * kD;
+    if (has_next) my_src_n = pos[min(tile_row0_n + r, row_end_n - 1)];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int t = 2 * sl + q;
-      M3_DIAG(const unsigned long long c0 = __builtin_amdgcn_s_memtime();)
-      if (t > 0) __syncthreads();
-      M3_DIAG(const unsigned long long c1 = __builtin_amdgcn_s_memtime();)
-      const bool has1 = t + 1 < np, has2 = t + 2 < np;
-      const int sl_next = abs_slice(sl + 1 < nsl ? sl + 1 : sl);
-      auto service = [&](int ii) {
-        if (has1) store_kb(q ^ 1, q ^ 1, ii);          // piece t + 1 has the other q and the other slot
-        if (has2) load_kb(sl_next, q, ii);
-      };
-      const char* slot = smem + q * kPiece;
-      if (q == 0) gemm1(slot, abs_slice(sl) - sl0, service);
-      else gemm2(slot, abs_slice(sl) - sl0, service);
-      M3_DIAG(asm volatile("s_nop 0" ::: "memory"); const unsigned long long c4 = __builtin_amdgcn_s_memtime();
-              dg[0] += c1 - c0; if (q == 0) dg[3] += c4 - c1; else dg[4] += c4 - c1;)
-    }
-  }
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accy[i][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+a"(accy[i]));
+    // settle the pos load HERE (behind the zeroing): a load still pending in hipcc's model at the loop head would put an
+    // s_waitcnt vmcnt(0) in front of every fill of the loop, draining the weight loads in flight each time
+    asm volatile("" : "+v"(my_src_n));
 
-  M3_DIAG(if (lane == 0 && blockIdx.x < 1024) {
-    unsigned long long* o = g_fused8_dbg + (blockIdx.x * 4 + wv) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = dg[i];
-    o[5] = __builtin_amdgcn_s_memtime() - t_begin;
-    o[6] = t_begin - t_k0;                             // prologue: X load + quantisation, first pieces
-  })
-  // ---- epilogue: Y[tok][d] = accy * s2[d] * h_scale, d = 32 db + (i & 3) + 8 (i >> 2) + 4 h.  A lane holds one token's
-  //      column strip; writing it out directly would touch 64 rows per store instruction in 16-B pieces.  So 128 columns
-  //      at a time go through the wave-private LDS image [32 tokens][528 B] and leave as whole 512-B row segments ----
-  __syncthreads();                                     // every wave is past its last fragment read
-  {
-    constexpr int kYs = 528;
-    char* ys = smem + wv * (32 * kYs);
-    const int tile_row0 = row_begin + tt * kTok + wv * 32;
-    const float* s2r = s2 + (size_t)e * kD + 4 * h;
+    M3_DIAG(const unsigned long long t_begin = __builtin_amdgcn_s_memtime();)
+    // step t: barrier (every wave is done reading slot (t + 1) & 1, piece t is visible) -> MFMAs on piece t, and between the
+    // MFMA batches, KB by KB: ds_write piece t + 1 (arrived during step t - 1) into the other slot, load piece t + 2
+    for (int sl = 0; sl < nsl; ++sl) {
+      const bool last_sl = sl + 1 == nsl;
+      const unsigned char* wa = last_sl ? w1n : w1e;   // piece t + 2 of the last slice's steps = piece 0 / 1 of the next tile
+      const unsigned char* wb = last_sl ? w2n : w2e;
+      int sl_next = abs_slice(sl + 1);
+      if (last_sl) sl_next = sl0_n + phase0_n;
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
+      for (int q = 0; q < 2; ++q) {
+        const int t = 2 * sl + q;
+        M3_DIAG(const unsigned long long c0 = __builtin_amdgcn_s_memtime();)
+        __syncthreads();
+        M3_DIAG(const unsigned long long c1 = __builtin_amdgcn_s_memtime();)
+        const bool xq_step = has_next && t >= 1 && t <= 16, xi_step = has_next && t < 16;
+        auto service = [&](int ii) {
+          // vmcnt arithmetic: every service issues exactly one load; row A's fills are issued after load 1,
+          // row B's after load 5 -> 8 VMEM operations are younger than a row's fills when it is quantised a step later
+          // (6 for row B at t = 16, when no further fills follow)
+          if (xq_step && ii == 0) {
+            wait_vmcnt<8>();
+            x_quant(2 * (t - 1));
+          }
+          if (xq_step && ii == 4) {
+            if (t == 16) wait_vmcnt<6>(); else wait_vmcnt<8>();
+            x_quant(2 * (t - 1) + 1);
+          }
+          // (unconditional: past the work-group's last piece the stream re-loads that tile's first pieces into slots nobody
+          //  reads any more -- straight-line code keeps hipcc's vmcnt arithmetic exact)
+          store_kb(q ^ 1, q ^ 1, ii);                  // piece t + 1 has the other q and the other slot
+          load_kb(wa, wb, sl_next, q, ii);
+          if (xi_step && ii == 1) x_issue(2 * t);
+          if (xi_step && ii == 5) x_issue(2 * t + 1);
+        };
+        const char* slot = smem + q * kPiece;
+        if (q == 0) gemm1(slot, abs_slice(sl) - sl0, service);
+        else gemm2(slot, abs_slice(sl) - sl0, service);
+        M3_DIAG(asm volatile("s_nop 0" ::: "memory"); const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                dg[0] += c1 - c0; if (q == 0) dg[3] += c4 - c1; else dg[4] += c4 - c1;)
+      }
+    }
+    M3_DIAG(const unsigned long long t_loop = __builtin_amdgcn_s_memtime(); dg[5] += t_loop - t_begin;)
+
+    // ---- tile end: the next tile's small operands, this tile's output, then the next tile's X fragments ----
+    __syncthreads();                                   // every wave is past its last b1 / s1 read and its last read of slot 1
+    if (has_next) {
+      // (all loads of this section are consumed before the first Y store is issued: a wait for a load issued after the
+      //  stores would wait for the stores as well, and they are meant to drain under the next tile's MFMAs)
+      if ((nxt.e != cur.e || nxt.fs != cur.fs) && threadIdx.x * 4 < nsl * 64) {
+        *reinterpret_cast<f32x4*>(b1_lds + threadIdx.x * 4) = ldg4(b1 + (size_t)nxt.e * F + sl0_n * 64 + threadIdx.x * 4);
+        *reinterpret_cast<f32x4*>(s1_lds + threadIdx.x * 4) = ldg4(s1 + (size_t)nxt.e * F + sl0_n * 64 + threadIdx.x * 4);
+      }
+      s2h_lds[(par ^ 1) * 512 + threadIdx.x] = s2[(size_t)nxt.e * kD + threadIdx.x] * h_scale;
+      s2h_lds[(par ^ 1) * 512 + threadIdx.x + 256] = s2[(size_t)nxt.e * kD + threadIdx.x + 256] * h_scale;
+      // X rows the loop did not get to (short loops: np < 17): pending fills first, then the rest directly
+      const int issued = 2 * min(np, 16), done = 2 * (min(np, 17) - 1);
+      if (done < issued) {
+        wait_vmcnt<0>();
+        for (int i = done; i < issued; ++i) x_quant(i);
+      }
+      for (int i = issued; i < 32; i += 2) {
+        x_issue(i);
+        x_issue(i + 1);
+        wait_vmcnt<0>();
+        x_quant(i);
+        x_quant(i + 1);
+      }
+    }
+    M3_DIAG(const unsigned long long t_mid = __builtin_amdgcn_s_memtime(); dg[2] += t_mid - t_loop;)
+    // Y[tok][d] = accy * s2[d] * h_scale, d = 32 db + (i & 3) + 8 (i >> 2) + 4 h.  A lane holds one token's column strip;
+    // writing it out directly would touch 64 rows per store instruction in 16-B pieces.  So 64 columns at a time go through
+    // this wave's quarter of weight slot 1 (free between the last step of a tile and the first service of the next) as
+    // [32 tokens][256 B], 16-B chunks XOR-swizzled by the row, and leave as 256-B row segments.  The stores are not waited
+    // for: they drain under the next tile's MFMAs; nothing between the first store and the next tile's loop touches vmcnt.
+    {
+      int le = lane;                                   // opaque copy: keeps the epilogue's per-lane addresses out of the
+      asm volatile("" : "+v"(le));                     // registers that live across the whole tile loop
+      const int er = le & 31, eh = le >> 5, rrow = le >> 4, rc = le & 15;
+      char* ys = smem + kPiece + wv * 8192;
+      const float* sc = s2h_lds + par * 512 + 4 * eh;
+      float* yrow = ybuf + ((size_t)cur.fs * S + tile_row0) * kD + 4 * rc;
 #pragma unroll
-      for (int dbl = 0; dbl < 4; ++dbl) {
-        const int db = 4 * g4 + dbl;
+      for (int p8 = 0; p8 < 8; ++p8) {
+        __builtin_amdgcn_sched_barrier(0);               // (keeps hipcc from hoisting later passes' scale reads and spilling them)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const f32x4 sc = ldg4(s2r + 32 * db + 8 * m);
-          *reinterpret_cast<f32x4*>(ys + r * kYs + (32 * dbl + 8 * m + 4 * h) * 4) =
-              f32x4{accy[db][4 * m] * (sc[0] * h_scale), accy[db][4 * m + 1] * (sc[1] * h_scale),
-                    accy[db][4 * m + 2] * (sc[2] * h_scale), accy[db][4 * m + 3] * (sc[3] * h_scale)};
+        for (int dbl = 0; dbl < 2; ++dbl) {
+          const int db = 2 * p8 + dbl;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + 32 * db + 8 * m);
+            const int c = 8 * dbl + 2 * m + eh;
+            *reinterpret_cast<f32x4*>(ys + er * 256 + ((c ^ (er & 15)) << 4)) =
+                f32x4{accy[db][4 * m] * s4[0], accy[db][4 * m + 1] * s4[1], accy[db][4 * m + 2] * s4[2], accy[db][4 * m + 3] * s4[3]};
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                      // instruction i: tokens 4 i .. 4 i + 3, 256 B each
+          const int tok = 4 * i + rrow;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ys + tok * 256 + ((rc ^ (tok & 15)) << 4));
+          if (tile_row0 + tok < row_end) store16_nt_hidden(yrow + (size_t)tok * kD + 64 * p8, v);
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {                     // instruction i: tokens 2 i, 2 i + 1, 512 B each
-        const int tok = 2 * i + (lane >> 5);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ys + tok * kYs + (lane & 31) * 16);
-        if (tile_row0 + tok < row_end)
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ybuf + ((size_t)fs * S + tile_row0 + tok) * kD + 128 * g4 + 4 * (lane & 31)));
-      }
     }
+    M3_DIAG(dg[1] += __builtin_amdgcn_s_memtime() - t_mid;)
+    if (!has_next) break;
+    read_xq();
+    par ^= 1;
+    item = item_n;
+    cur = nxt;
+    row_end = row_end_n;
+    tile_row0 = tile_row0_n;
+    sl0 = sl0_n;
+    phase0 = phase0_n;
+    w1e = w1n;
+    w2e = w2n;
+    sx = sx_n;
   }
   M3_DIAG(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0 && blockIdx.x < 1024) g_fused8_dbg[(blockIdx.x * 4 + wv) * 8 + 7] = __builtin_amdgcn_s_memtime() - t_k0;)
+          if (lane == 0 && blockIdx.x < 1024) {
+            unsigned long long* o = g_fused8_dbg + (blockIdx.x * 4 + wv) * 8;
+            for (int i = 0; i < 7; ++i) o[i] = dg[i];
+            o[7] = __builtin_amdgcn_s_memtime() - t_k0;
+          })
 }
 
 // ---- host side ----
@@ -406,11 +586,26 @@ static int fused8_min_rows() {
 }
 int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F) {
   const int tiles = cdiv(S, kTok) + E / 2;
-  if (F % 512 == 0 && tiles < 112) return 4;
-  return (tiles < 224 && F % 256 == 0) ? 2 : 1;
+  int fs = 1;
+  if (F % 512 == 0 && tiles < 112) fs = 4;
+  else if (tiles < 224 && F % 256 == 0) fs = 2;
+  while (F / fs > 1024 && fs < 4) fs *= 2;                   // b1 / s1 of a work item's F range: 1024 floats each in LDS
+  return fs;
 }
 bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F) {
-  return D == kD && F % 128 == 0 && F <= 4096 && S >= fused8_min_rows() && S >= 64 * E && E <= 1024;
+  if (!(D == kD && F % 128 == 0 && F <= 4096 && S >= fused8_min_rows() && S >= 64 * E && E <= 1024)) return false;
+  const int fs = expert_ffn_fused_fp8_fsplit(S, E, D, F);
+  return F % (128 * fs) == 0 && F / fs <= 1024;
+}
+// persistent grid: one work-group per CU, a multiple of 8 (XCDs)
+static int fused8_grid() {
+  static int g = 0;
+  if (!g) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    g = cus >= 8 ? cus / 8 * 8 : 8;
+  }
+  return g;
 }
 int init_expert_ffn_fused_fp8_kernels() {
   static bool done = false;
@@ -430,14 +625,14 @@ int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, con
   M3_REQUIRE(h_scale > 0.f, "expert_ffn_fused_fp8: h_scale must be positive (got %g)", (double)h_scale);
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   const int fsplit = expert_ffn_fused_fp8_fsplit(S, E, D, F);
-  const int tiles = cdiv(S, kTok) + E;
-  const int nblk = cdiv(tiles * fsplit, 8) * 8;
+  M3_REQUIRE((size_t)S * ldx * 4 < ((size_t)1 << 32), "expert_ffn_fused_fp8: input of %d rows x %d floats exceeds a 4-GB buffer", S, ldx);
+  const int nblk = fused8_grid();
   const int row_stride = w2_sliced ? 64 : F;                 // bytes between consecutive d rows of W2
   const int slice_stride = w2_sliced ? D * 64 : 64;          // bytes between consecutive 64-wide f slices
-  const size_t lds = (size_t)kRing * kPiece + (size_t)(F / fsplit) * 2 * sizeof(float);
+  const size_t lds = kLdsBytes;
 #define M3_FUSED8_LAUNCH(FS_)                                                                                              \
   hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, E, \
-                     F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride, h_scale, ybuf, nblk)
+                     F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride, h_scale, ybuf)
   if (fsplit == 4) M3_FUSED8_LAUNCH(4); else if (fsplit == 2) M3_FUSED8_LAUNCH(2); else M3_FUSED8_LAUNCH(1);
 #undef M3_FUSED8_LAUNCH
   M3_LAUNCH_CHECK();

@@ -103,7 +103,11 @@ def _q8(t):
 
 @pytest.mark.parametrize("S,E,D,Fh,mode", [(4096, 32, 512, 1024, "uniform"), (16384, 32, 512, 1024, "uniform"),
                                            (6500, 8, 512, 1024, "with_dropped"), (9000, 64, 512, 1024, "uniform"),
-                                           (40000, 32, 512, 1024, "with_dropped"), (5000, 16, 512, 2048, "all_one")])
+                                           (40000, 32, 512, 1024, "with_dropped"), (5000, 16, 512, 2048, "all_one"),
+                                           # persistent work-groups with several tiles each: F split in 2 / 4 (short piece
+                                           # loops: part of the next tile's rows is fetched at the tile end), and 2 full tiles
+                                           (20000, 32, 512, 1024, "uniform"), (10000, 32, 512, 1024, "uniform"),
+                                           (65536, 32, 512, 1024, "uniform")])
 def test_fmoe_expert_fp8_arithmetic(S, E, D, Fh, mode):
     """fp8 ARITHMETIC (m3_moe_expert_ffn_fp8a8: e4m3 weights x e4m3 activations, v_mfma_f32_32x32x16_fp8_fp8) against an
     fp64 evaluation of exactly the quantised computation it defines: rows quantised with the per-row scale amax / 448, H with

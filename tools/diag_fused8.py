@@ -23,8 +23,8 @@ buf = np.zeros(4096 * 8, dtype=np.uint64)
 lib.m3_debug_fused8_read.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 lib.m3_debug_fused8_read(buf.ctypes.data, buf.nbytes)
 d = buf.reshape(-1, 8).astype(np.float64)
-d = d[d[:, 5] > 0]
-names = ["vmcnt wait", "barrier", "fill issue", "gemm1+silu+quant", "gemm2"]
-tot = np.median(d[:, 5])
-print("prologue median %.0f cycles, whole kernel per wave median %.0f (p90 %.0f)" % (np.median(d[:, 6]), np.median(d[:, 7]), np.percentile(d[:, 7], 90)))
-print("waves %d, total median %.0f cycles; " % (len(d), tot) + ", ".join("%s %.0f (%.0f%%)" % (n, np.median(d[:, i]), 100 * np.median(d[:, i]) / tot) for i, n in enumerate(names)))
+d = d[d[:, 7] > 0]
+names = ["barrier", "epilogue (Y out)", "tile end (bias, X flush, xq)", "gemm1+silu+quant", "gemm2", "piece loops", "prologue"]
+tot = np.median(d[:, 7])
+print("waves %d; whole kernel per wave median %.0f cycles (p90 %.0f); " % (len(d), tot, np.percentile(d[:, 7], 90)))
+print("  " + ", ".join("%s %.0f (%.0f%%)" % (n, np.median(d[:, i]), 100 * np.median(d[:, i]) / tot) for i, n in enumerate(names)))
