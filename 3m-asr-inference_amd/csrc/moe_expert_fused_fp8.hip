@@ -33,6 +33,7 @@
 namespace m3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // diagnostic build (-DM3_FUSED_DIAG): shader-clock cycles per wave spent in the counted wait, the barrier, issuing the
 // LDS-DMA fills, GEMM-1 (+ SiLU + quantisation) and GEMM-2; read back with m3_debug_fused8_read.  Not in the product build.
@@ -46,7 +47,9 @@ __device__ unsigned long long g_fused8_dbg[4096 * 8];
 namespace {
 
 constexpr int kTok = 128;            // tokens per work-group (4 waves x 32)
-constexpr int kPiece = 32768;        // bytes per ring slot = one 64-wide slice of W1 (64 rows x 512 B) or of W2 (512 rows x 64 B)
+constexpr int kPiece = 32768;        // bytes per piece = one 64-wide slice of W1 (64 rows x 512 B) or of W2 (512 rows x 64 B)
+constexpr int kW1Row = 528;          // W1 rows are padded to 528 B in LDS: conflict-free ds_read_b128 at base + immediate
+constexpr int kSlot = 64 * kW1Row;   // bytes per LDS slot (33792)
 constexpr int kRing = 2;
 constexpr int kD = 512;
 
@@ -77,6 +80,48 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ f32x16 mfma8(long a, long b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
 }
+// GEMM-1's two z blocks must live in ARCH VGPRs (SiLU reads them with VALU instructions); hipcc gives every MFMA result an
+// AGPR home and, with all 256 AGPRs taken by the output tile, parks two output blocks in VGPRs around GEMM-1 and copies the z
+// blocks out again (~250 v_accvgpr moves per slice).  Inline assembly pins the register class.  Hazards: dependent MFMAs
+// on the same accumulator issue back to back (hipcc does the same); hipcc does not know that the asm result comes from
+// the matrix pipe and may schedule a VALU read of it right behind the last MFMA, so every chain ends with mfma8_v_settle
+// (24 wait states >= the 19 a 16-pass MFMA needs before a VALU read); operands come from ds_read (hipcc waits on
+// lgkmcnt for asm inputs) or are long-lived.
+#ifndef M3_F8_ASM_MFMA
+#define M3_F8_ASM_MFMA 1
+#endif
+#if M3_F8_ASM_MFMA
+__device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
+  asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) {
+  asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+#else
+__device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
+  f32x16 z;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) z[j] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, z, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) { c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0); }
+#endif
+__device__ __forceinline__ void mfma8_v_settle(f32x16& c) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c)); }
+// max over the 64 lanes without the LDS pipe: DPP inside rows of 16, then
+__device__ __forceinline__ float wave_max_valu(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));  // row_mirror
+  // across the four rows through SGPRs (v_readlane).  (v_permlane16_swap / v_permlane32_swap would do it in two VALU steps,
+  // but hipcc folds max(swap(x, x')[0], swap(x, x')[1]) to the first element -- measured: wrong row maxima.)
+  const int u = __builtin_bit_cast(int, v);
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
+  return v;
+}
 __device__ __forceinline__ float clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }
 // 8 floats -> 8 e4m3 bytes (element j in byte j)
 __device__ __forceinline__ long q8(const float* v, float inv) {
@@ -85,6 +130,15 @@ __device__ __forceinline__ long q8(const float* v, float inv) {
   lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), lo, true);
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4] * inv), clamp448(v[5] * inv), hi, false);
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[6] * inv), clamp448(v[7] * inv), hi, true);
+  return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// the same for values that are already in units of the scale
+__device__ __forceinline__ long q8s(const float* v) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0]), clamp448(v[1]), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2]), clamp448(v[3]), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4]), clamp448(v[5]), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[6]), clamp448(v[7]), hi, true);
   return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 // LDS row rho (0..31) of a W1 block holds the block's row pi8(rho): rho = 16 s + 8 a + 4 h + b  ->  16 h + 8 s + 4 a + b
@@ -124,11 +178,10 @@ __device__ __forceinline__ TileRef find_tile(const int32_t* __restrict__ acc_his
   return TileRef{__builtin_amdgcn_readfirstlane(e), __builtin_amdgcn_readfirstlane(tt), item - tile * fsplit};
 }
 
-// LDS map (bytes): [0, 64 K) two 32-KB weight slots (slot 1 doubles as the Y staging area between two tiles) | [64 K, 72 K) b1,
-// s1 of the current tile's F range (<= 1024 floats each) | [72 K, 76 K) s2 * h_scale of the current / next tile's expert
-// | [76 K, 142 K) four wave-private X images [32 rows][528 B] (e4m3) | [142 K, 158 K) four wave-private raw rows x 2 (the
-// next tile's X arriving by LDS-DMA)
-constexpr int kOffBias = kRing * kPiece;
+// LDS map (160 KB, all of it): two 33-KB weight slots (slot 1 doubles as the Y staging area between two tiles) | 8 KB b1, s1 of
+// the current tile's F range (<= 1024 floats each) | 4 KB s2 * h_scale of the current / next tile's expert | 66 KB four
+// wave-private X images [32 rows][528 B] (e4m3) | 16 KB four wave-private raw rows x 2 (the next tile's X arriving by LDS-DMA)
+constexpr int kOffBias = kRing * kSlot;
 constexpr int kOffS2 = kOffBias + 8192;
 constexpr int kOffImg = kOffS2 + 4096;
 constexpr int kImgRow = 528;
@@ -207,7 +260,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
     amax = fmaxf(wave_max(amax), 1e-30f);
-    const float inv = 448.f / amax;
+    const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if (r == i) sxv = amax * (1.f / 448.f);
     int q0 = 0, q1 = 0;
     q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[0] * inv), clamp448(v0[1] * inv), q0, false);
@@ -269,36 +322,48 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     dma16_hidden(rsx, voff, soff, dst);                   // (asm volatile + memory clobber: no load is moved across the
     dma16_hidden(rsx, voff + 1024u, soff, dst + 1024u);   // fills; the counted waits rely on the issue order)
   };
-  auto x_quant = [&](int i) {                           // (after the wait for row i's two fills)
-    // one 16-B piece of the row in registers at a time (the row is read three times from LDS instead of held in 8 VGPRs)
+  // quantisation of an arrived row in two parts, each with ONE LDS round trip (the wave stalls on every lgkmcnt wait -- it is
+  // the only wave of its SIMD): part 1 reads the row and keeps only its partial amax, part 2 (a service later) reduces it over
+  // the wave without the LDS pipe, re-reads the row and converts it
+  float x_amax = 0.f;
+  auto x_quant1 = [&](int i) {                          // (after the wait for row i's two fills)
+    const char* src = rawb + (i & 1) * 2048 + olane() * 16;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
+    x_amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                   fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  };
+  auto x_quant2 = [&](int i) {
     const int l = olane();
     const char* src = rawb + (i & 1) * 2048 + l * 16;
-    f32x4 v = *reinterpret_cast<const f32x4*>(src);
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    __builtin_amdgcn_sched_barrier(0);
-    v = *reinterpret_cast<const f32x4*>(src + 1024);
-    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    amax = fmaxf(wave_max(amax), 1e-30f);
-    const float inv = 448.f / amax;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
+#ifdef M3_F8_DBG_OLDMAX
+    const float amax = fmaxf(wave_max(x_amax), 1e-30f);
+#else
+    const float amax = fmaxf(wave_max_valu(x_amax), 1e-30f);
+#endif
+    const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if ((l & 31) == i) sx_n = amax * (1.f / 448.f);
-    int q = 0;
-    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), q, false);
-    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), q, true);
-    *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * l) = q;
-    __builtin_amdgcn_sched_barrier(0);
-    v = *reinterpret_cast<const f32x4*>(src);
-    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), q, false);
-    q = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), q, true);
-    *reinterpret_cast<int*>(img + i * kImgRow + 4 * l) = q;
+    int q0 = 0, q1 = 0;
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[0] * inv), clamp448(v0[1] * inv), q0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[2] * inv), clamp448(v0[3] * inv), q0, true);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[0] * inv), clamp448(v1[1] * inv), q1, false);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[2] * inv), clamp448(v1[3] * inv), q1, true);
+    *reinterpret_cast<int*>(img + i * kImgRow + 4 * l) = q0;
+    *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * l) = q1;
+  };
+  auto x_quant = [&](int i) {
+    x_quant1(i);
+    x_quant2(i);
   };
 
   // ---- weight staging through registers: wave wv brings KB 8 wv .. 8 wv + 7 of every 32-KB piece, natural (fully
   //      coalesced) source order; the row permutation pi8 and the bank swizzles are applied to the LDS DESTINATION ----
-  // W1 piece = 64 rows x 512 B.  LDS row rho of a piece holds the row f = 32 (rho >> 5) + pi8(rho & 31) of the slice; 16-B
-  //   chunk c of a row sits at physical chunk (c & 16) | ((c ^ rho) & 15).  Instruction ii of wave wv covers four HALF rows
-  //   (16 lanes x 16 B = 256 B each): rho = 16 (ii >> 1) + 4 wv + (lane >> 4), half ii & 1 -- the low four bits of rho (the
-  //   XOR key) and the row-dependent part of f then depend on the lane only, so source and destination are ONE per-lane
-  //   base each plus immediates (no per-instruction address registers)
+  // W1 piece = 64 rows x 512 B.  LDS row rho of a piece (rows padded to 528 B) holds the row f = 32 (rho >> 5) +
+  //   pi8(rho & 31) of the slice.  Instruction ii of wave wv covers four HALF rows (16 lanes x 16 B = 256 B each):
+  //   rho = 16 (ii >> 1) + 4 wv + (lane >> 4), half ii & 1 -- the row-dependent part of f depends on the lane only, so source
+  //   and destination are ONE per-lane base each plus immediates
   // W2 piece = 512 rows x 64 B: instruction ii covers rows 128 wv + 16 ii + (lane >> 2); chunk c = lane & 3 goes to physical
   //   chunk c ^ ((row >> 2) & 3) (independent of ii)
   u32x4 stg[8];                                        // the piece in flight (this wave's 8 KB)
@@ -316,19 +381,18 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     }
   };
   auto store_kb = [&](int q, int slot_i, int ii) {
-    char* dst = smem + slot_i * kPiece;
+    char* dst = smem + slot_i * kSlot;
     const int l = olane();
     if (q == 0) {
-      const int rho_l = 4 * wv + (l >> 4);
-      const unsigned dst1_lane = (unsigned)(rho_l * 512 + (((l & 15) ^ rho_l) << 4));
-      *reinterpret_cast<u32x4*>(dst + dst1_lane + (ii >> 1) * 8192 + (ii & 1) * 256) = stg[ii];
+      const unsigned dst1_lane = (unsigned)((4 * wv + (l >> 4)) * kW1Row + (l & 15) * 16);
+      *reinterpret_cast<u32x4*>(dst + dst1_lane + (ii >> 1) * (16 * kW1Row) + (ii & 1) * 256) = stg[ii];
     } else {
       const unsigned dst2_lane = (unsigned)((128 * wv + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4));
       *reinterpret_cast<u32x4*>(dst + dst2_lane + ii * 1024) = stg[ii];
     }
   };
 
-  // fragment read addresses: W1 block fb, step pair m: byte fb * 16384 + (rd1 ^ (m << 5)), rd1 = (r << 9) | ((h ^ (r & 15)) << 4)
+  // fragment read addresses: W1 block fb, step pair m: byte fb * 32 * 528 + r * 528 + 16 h + 32 m (padded rows: no swizzle)
   //                          W2 block db, step pair m: byte db * 2048 + (rd2 ^ (m << 5)), rd2 = (r << 6) | ((h ^ ((r >> 2) & 3)) << 4)
 
   f32x16 accy[16];
@@ -343,7 +407,6 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     load_kb(w1e, w2e, abs_slice(0), 1, ii);            // piece 1 in flight
   }
 
-  const float inv_h = 1.f / h_scale;
   long hq[2][2];                                       // Hq fragments of the current slice: [f block][k-step of the block]
 
   auto lo64 = [](const u32x4& a) { return (long)(((unsigned long long)a[1] << 32) | a[0]); };
@@ -351,50 +414,59 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   // SiLU + quantisation of a finished 32 x 32 block of z, a quarter (registers 4 q4 .. 4 q4 + 3 = f 32 fb + 16 h + 4 q4 ..)
   // at a time: the quarters are issued between the MFMA batches of the NEXT block, so the VALU work runs in the MFMAs' shadow;
   // two quarters make the 8 bytes of one k-step of GEMM-2's B operand
+  // Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction) and the H scale folded into the
+  // sigmoid's denominator: H / h_scale = z / ((1 + 2^(-z log2 e)) h_scale) -- the step is bound by VALU issue, not by MFMAs
   float hv[8];
+  const f32x2 hs2 = {h_scale, h_scale};
   auto silu_quarter = [&](const f32x16& acc, int sl_rel, int fb, int q4) {
     const int fo = sl_rel * 64 + fb * 32 + 16 * (olane() >> 5) + 4 * q4;
     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + fo);
     const f32x4 ss = *reinterpret_cast<const f32x4*>(s1_lds + fo);
+    const f32x2 sx2 = {sx, sx};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = acc[4 * q4 + j] * (ss[j] * sx) + bb[j];
-      hv[4 * (q4 & 1) + j] = z * __builtin_amdgcn_rcpf(1.f + __expf(-z));
+    for (int p = 0; p < 2; ++p) {
+      const f32x2 a2 = {acc[4 * q4 + 2 * p], acc[4 * q4 + 2 * p + 1]};
+      const f32x2 sc = f32x2{ss[2 * p], ss[2 * p + 1]} * sx2;
+      const f32x2 z = __builtin_elementwise_fma(a2, sc, f32x2{bb[2 * p], bb[2 * p + 1]});
+      const f32x2 t = z * f32x2{-1.44269504088896f, -1.44269504088896f};
+      const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      const f32x2 d = __builtin_elementwise_fma(e, hs2, hs2);
+      const f32x2 hh = z * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+      hv[4 * (q4 & 1) + 2 * p] = hh[0];
+      hv[4 * (q4 & 1) + 2 * p + 1] = hh[1];
     }
-    if (q4 & 1) hq[fb][q4 >> 1] = q8(hv, inv_h);
+    if (q4 & 1) hq[fb][q4 >> 1] = q8s(hv);
   };
   f32x16 acc_a, acc_b;                                 // z blocks fb = 0 / 1 of the current slice
   // fragment reads run two batches of 2 (8 VGPRs each, 4 k-steps) ahead of the MFMAs that consume them (ring of three)
   auto chain1 = [&](const char* blk, f32x16& acc, auto&& between) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    asm volatile("" : "+v"(acc));                       // z blocks live in arch VGPRs (SiLU reads them), the output tile in AGPRs
     const int l = olane();
-    const int rb = ((l & 31) << 9) | (((l >> 5) ^ (l & 15)) << 4);
+    const char* rp = blk + (l & 31) * kW1Row + (l >> 5) * 16;
     u32x4 a[3][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j >> 1][j & 1] = *reinterpret_cast<const u32x4*>(blk + (rb ^ (j << 5)));
+    for (int j = 0; j < 4; ++j) a[j >> 1][j & 1] = *reinterpret_cast<const u32x4*>(rp + j * 32);
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
       if (bb + 2 < 8) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          a[(bb + 2) % 3][j] = *reinterpret_cast<const u32x4*>(blk + (rb ^ ((2 * bb + 4 + j) << 5)));
+          a[(bb + 2) % 3][j] = *reinterpret_cast<const u32x4*>(rp + (2 * bb + 4 + j) * 32);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int m = 2 * bb + j;
-        acc = mfma8(lo64(a[bb % 3][j]), xq[2 * m], acc);
-        acc = mfma8(hi64(a[bb % 3][j]), xq[2 * m + 1], acc);
+        if (m == 0) mfma8_v0(acc, lo64(a[bb % 3][j]), xq[0]);
+        else mfma8_v(acc, lo64(a[bb % 3][j]), xq[2 * m]);
+        mfma8_v(acc, hi64(a[bb % 3][j]), xq[2 * m + 1]);
       }
       if (bb & 1) between(bb >> 1);
     }
-    asm volatile("" : "+v"(acc));
+    mfma8_v_settle(acc);
   };
   // step q = 0 of a slice: z block 0, then z block 1 with SiLU(block 0) in its shadow; SiLU(block 1) runs in GEMM-2's shadow
   auto gemm1 = [&](const char* slot, int sl_rel, auto&& service) {
     chain1(slot, acc_a, [&](int b) { service(b); });
-    chain1(slot + 16384, acc_b, [&](int b) {
+    chain1(slot + 32 * kW1Row, acc_b, [&](int b) {
       silu_quarter(acc_a, sl_rel, 0, b);
       service(4 + b);
     });
@@ -456,6 +528,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     M3_DIAG(const unsigned long long t_begin = __builtin_amdgcn_s_memtime();)
     // step t: barrier (every wave is done reading slot (t + 1) & 1, piece t is visible) -> MFMAs on piece t, and between the
     // MFMA batches, KB by KB: ds_write piece t + 1 (arrived during step t - 1) into the other slot, load piece t + 2
+#pragma clang loop unroll(disable)
     for (int sl = 0; sl < nsl; ++sl) {
       const bool last_sl = sl + 1 == nsl;
       const unsigned char* wa = last_sl ? w1n : w1e;   // piece t + 2 of the last slice's steps = piece 0 / 1 of the next tile
@@ -473,6 +546,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
           // vmcnt arithmetic: every service issues exactly one load; row A's fills are issued after load 1,
           // row B's after load 5 -> 8 VMEM operations are younger than a row's fills when it is quantised a step later
           // (6 for row B at t = 16, when no further fills follow)
+#ifdef M3_F8_DBG_UNSPLIT
           if (xq_step && ii == 0) {
             wait_vmcnt<8>();
             x_quant(2 * (t - 1));
@@ -481,6 +555,18 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
             if (t == 16) wait_vmcnt<6>(); else wait_vmcnt<8>();
             x_quant(2 * (t - 1) + 1);
           }
+#else
+          if (xq_step && ii == 0) {
+            wait_vmcnt<8>();
+            x_quant1(2 * (t - 1));
+          }
+          if (xq_step && ii == 1) x_quant2(2 * (t - 1));  // (before this service's fill of the same raw row: x_issue waits lgkmcnt)
+          if (xq_step && ii == 4) {
+            if (t == 16) wait_vmcnt<6>(); else wait_vmcnt<8>();
+            x_quant1(2 * (t - 1) + 1);
+          }
+          if (xq_step && ii == 5) x_quant2(2 * (t - 1) + 1);
+#endif
           // (unconditional: past the work-group's last piece the stream re-loads that tile's first pieces into slots nobody
           //  reads any more -- straight-line code keeps hipcc's vmcnt arithmetic exact)
           store_kb(q ^ 1, q ^ 1, ii);                  // piece t + 1 has the other q and the other slot
@@ -488,7 +574,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
           if (xi_step && ii == 1) x_issue(2 * t);
           if (xi_step && ii == 5) x_issue(2 * t + 1);
         };
-        const char* slot = smem + q * kPiece;
+        const char* slot = smem + q * kSlot;
         if (q == 0) gemm1(slot, abs_slice(sl) - sl0, service);
         else gemm2(slot, abs_slice(sl) - sl0, service);
         M3_DIAG(asm volatile("s_nop 0" ::: "memory"); const unsigned long long c4 = __builtin_amdgcn_s_memtime();
@@ -532,7 +618,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
       int le = lane;                                   // opaque copy: keeps the epilogue's per-lane addresses out of the
       asm volatile("" : "+v"(le));                     // registers that live across the whole tile loop
       const int er = le & 31, eh = le >> 5, rrow = le >> 4, rc = le & 15;
-      char* ys = smem + kPiece + wv * 8192;
+      char* ys = smem + kSlot + wv * 8192;
       const float* sc = s2h_lds + par * 512 + 4 * eh;
       float* yrow = ybuf + ((size_t)cur.fs * S + tile_row0) * kD + 4 * rc;
 #pragma unroll
