@@ -4,8 +4,8 @@
 // reference output for it, the arithmetic is defined here and tested against an fp64 evaluation of exactly this
 // quantised computation (tests/test_fp8_gpu.py).
 //
-// Quantisation (OCP e4m3fn, |max| = 448, conversions round to nearest even; values are clamped to +-448 first because
-// v_cvt_pk_fp8_f32 turns an out-of-range input into NaN on gfx950, it does not saturate):
+// Quantisation (OCP e4m3fn, |max| = 448, conversions round to nearest even and SATURATE to +-448: the kernel sets
+// MODE.FP16_OVFL, without which v_cvt_pk_fp8_f32 turns an out-of-range input into NaN on gfx950 -- tools/ubench/fp8_cvt_sat.hip):
 //   W1[e][f][:], W2[e][d][:]   e4m3 with one fp32 scale per output row (s1[e][f], s2[e][d]) -- the plan's fp8 format
 //   X[tok][:]                  e4m3 with a per-token DYNAMIC scale sx[tok] = amax(row) / 448, computed while the row is loaded
 //   H[tok][:]                  e4m3 with ONE static scale per layer, h_scale (from the calibrator: amax of H over the
@@ -77,9 +77,16 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+#ifdef M3_F8_NO_MFMA   // ablation build: everything but the matrix instructions (results are garbage)
+__device__ __forceinline__ f32x16 mfma8(long a, long b, f32x16 c) {
+  asm volatile("" : "+a"(c) : "v"(a), "v"(b));
+  return c;
+}
+#else
 __device__ __forceinline__ f32x16 mfma8(long a, long b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
 }
+#endif
 // GEMM-1's two z blocks must live in ARCH VGPRs (SiLU reads them with VALU instructions); hipcc gives every MFMA result an
 // AGPR home and, with all 256 AGPRs taken by the output tile, parks two output blocks in VGPRs around GEMM-1 and copies the z
 // blocks out again (~250 v_accvgpr moves per slice).  Inline assembly pins the register class.  Hazards: dependent MFMAs
@@ -90,7 +97,14 @@ __device__ __forceinline__ f32x16 mfma8(long a, long b, f32x16 c) {
 #ifndef M3_F8_ASM_MFMA
 #define M3_F8_ASM_MFMA 1
 #endif
-#if M3_F8_ASM_MFMA
+#ifdef M3_F8_NO_MFMA
+__device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) c[j] = 0.f;
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); }
+#elif M3_F8_ASM_MFMA
 __device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
   asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
@@ -135,10 +149,10 @@ __device__ __forceinline__ long q8(const float* v, float inv) {
 // the same for values that are already in units of the scale
 __device__ __forceinline__ long q8s(const float* v) {
   int lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0]), clamp448(v[1]), lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2]), clamp448(v[3]), lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4]), clamp448(v[5]), hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[6]), clamp448(v[7]), hi, true);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);       // (saturating: MODE.FP16_OVFL is set)
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
   return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 // LDS row rho (0..31) of a W1 block holds the block's row pi8(rho): rho = 16 s + 8 a + 4 h + b  ->  16 h + 8 s + 4 a + b
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);         // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL -- fp8 conversions saturate
   // The kernel runs at the register limit (256 accumulator + 256 other registers, one wave per SIMD).  Per-lane address
   // constants that live across the whole tile loop get spilled by hipcc -- and a scratch re-load inside the loop costs an
   // s_waitcnt vmcnt(0), i.e. a drain of the weight loads in flight.  So the hot loop RECOMPUTES them from the lane id at
@@ -263,10 +278,10 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if (r == i) sxv = amax * (1.f / 448.f);
     int q0 = 0, q1 = 0;
-    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[0] * inv), clamp448(v0[1] * inv), q0, false);
-    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[2] * inv), clamp448(v0[3] * inv), q0, true);
-    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[0] * inv), clamp448(v1[1] * inv), q1, false);
-    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[2] * inv), clamp448(v1[3] * inv), q1, true);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0] * inv, v1[1] * inv, q1, false);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2] * inv, v1[3] * inv, q1, true);
     *reinterpret_cast<int*>(img + i * kImgRow + 4 * lane) = q0;
     *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * lane) = q1;
   };
@@ -346,10 +361,10 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if ((l & 31) == i) sx_n = amax * (1.f / 448.f);
     int q0 = 0, q1 = 0;
-    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[0] * inv), clamp448(v0[1] * inv), q0, false);
-    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0[2] * inv), clamp448(v0[3] * inv), q0, true);
-    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[0] * inv), clamp448(v1[1] * inv), q1, false);
-    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v1[2] * inv), clamp448(v1[3] * inv), q1, true);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0] * inv, v1[1] * inv, q1, false);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2] * inv, v1[3] * inv, q1, true);
     *reinterpret_cast<int*>(img + i * kImgRow + 4 * l) = q0;
     *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * l) = q1;
   };
@@ -366,28 +381,28 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   //   and destination are ONE per-lane base each plus immediates
   // W2 piece = 512 rows x 64 B: instruction ii covers rows 128 wv + 16 ii + (lane >> 2); chunk c = lane & 3 goes to physical
   //   chunk c ^ ((row >> 2) & 3) (independent of ii)
+#ifndef M3_F8_RECOMPUTE_ADDR
+  const unsigned src1_lane = (unsigned)((16 * (wv & 1) + 4 * (wv >> 1) + (lane >> 4)) * 512 + (lane & 15) * 16);
+  const unsigned src2_lane = (unsigned)((128 * wv + (lane >> 2)) * w2_row_stride + (lane & 3) * 16);   // + ii * 16 rows + slice
+  const unsigned dst1_lane = (unsigned)((4 * wv + (lane >> 4)) * kW1Row + (lane & 15) * 16);
+  const unsigned dst2_lane = (unsigned)((128 * wv + (lane >> 2)) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+#endif
   u32x4 stg[8];                                        // the piece in flight (this wave's 8 KB)
   // one KB of the stream: ds_write the KB of piece t + 1 that arrived a step ago, then re-use its registers for the same KB
   // of piece t + 2.  A step spreads its 8 services between its MFMA batches: a wave that issues 8 loads back to back waits
   // ~160 cycles per load for the CU's load path (in-kernel stamps), one load per 8 MFMAs issues into an idle path.
   auto load_kb = [&](const unsigned char* wa, const unsigned char* wb, int sl, int q, int ii) {
-    const int l = olane();
     if (q == 0) {
-      const unsigned src1_lane = (unsigned)((16 * (wv & 1) + 4 * (wv >> 1) + (l >> 4)) * 512 + (l & 15) * 16);
       stg[ii] = *reinterpret_cast<const u32x4*>(wa + (size_t)sl * 32768 + src1_lane + ((ii & 1) * 256 + ((ii >> 1) & 1) * 4096 + (ii >> 2) * 16384));
     } else {
-      const unsigned src2_lane = (unsigned)((128 * wv + (l >> 2)) * w2_row_stride + (l & 3) * 16);   // + ii * 16 rows + slice
       stg[ii] = *reinterpret_cast<const u32x4*>(wb + (size_t)sl * w2_slice_stride + src2_lane + (size_t)ii * 16 * w2_row_stride);
     }
   };
   auto store_kb = [&](int q, int slot_i, int ii) {
     char* dst = smem + slot_i * kSlot;
-    const int l = olane();
     if (q == 0) {
-      const unsigned dst1_lane = (unsigned)((4 * wv + (l >> 4)) * kW1Row + (l & 15) * 16);
       *reinterpret_cast<u32x4*>(dst + dst1_lane + (ii >> 1) * (16 * kW1Row) + (ii & 1) * 256) = stg[ii];
     } else {
-      const unsigned dst2_lane = (unsigned)((128 * wv + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4));
       *reinterpret_cast<u32x4*>(dst + dst2_lane + ii * 1024) = stg[ii];
     }
   };
@@ -623,7 +638,10 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
       float* yrow = ybuf + ((size_t)cur.fs * S + tile_row0) * kD + 4 * rc;
 #pragma unroll
       for (int p8 = 0; p8 < 8; ++p8) {
-        __builtin_amdgcn_sched_barrier(0);               // (keeps hipcc from hoisting later passes' scale reads and spilling them)
+        __builtin_amdgcn_sched_barrier(0);
+        // (the two blocks of this pass stay in AGPRs until here: hipcc otherwise copies most of the output tile to VGPRs
+        //  ahead of the tile-end barrier and spills the loop's constants to make room)
+        asm volatile("" : "+a"(accy[2 * p8]), "+a"(accy[2 * p8 + 1]));
 #pragma unroll
         for (int dbl = 0; dbl < 2; ++dbl) {
           const int db = 2 * p8 + dbl;
