@@ -63,7 +63,7 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // fills themselves are written by hand (wait_vmcnt below).
 __device__ __forceinline__ void dma16_hidden(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");   // (m0 is reserved: hipcc re-loads it before its own uses)
 }
 // Y leaves through stores hipcc does not see either: with loads AND stores pending in its model (gfx9 counts both in vmcnt
 // and they may complete out of order), every later wait for a load becomes s_waitcnt vmcnt(0) until a vmcnt(0) is executed
@@ -106,10 +106,10 @@ __device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
 __device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); }
 #elif M3_F8_ASM_MFMA
 __device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
-  asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+  asm("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) {
-  asm volatile("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  asm("v_mfma_f32_32x32x16_fp8_fp8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 #else
 __device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
@@ -120,21 +120,22 @@ __device__ __forceinline__ void mfma8_v0(f32x16& c, long a, long b) {
 }
 __device__ __forceinline__ void mfma8_v(f32x16& c, long a, long b) { c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0); }
 #endif
-__device__ __forceinline__ void mfma8_v_settle(f32x16& c) { asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c)); }
-// max over the 64 lanes without the LDS pipe: DPP inside rows of 16, then
-__device__ __forceinline__ float wave_max_valu(float v) {
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));  // row_mirror
-  // across the four rows through SGPRs (v_readlane).  (v_permlane16_swap / v_permlane32_swap would do it in two VALU steps,
-  // but hipcc folds max(swap(x, x')[0], swap(x, x')[1]) to the first element -- measured: wrong row maxima.)
-  const int u = __builtin_bit_cast(int, v);
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
-  return v;
+__device__ __forceinline__ void mfma8_v_settle(f32x16& c) { asm("s_nop 15\n\ts_nop 7" : "+v"(c)); }
+// max of non-negative values over the 64 lanes, one instruction per step: v_max_f32 with a DPP source (hipcc's fmaxf costs
+// three: v_mov_dpp, a canonicalising v_max, v_max), rows of 16 first, then row_bcast 15 / 31 carry the row maxima to lane 63
+// and v_readlane brings the total back as a scalar.  (s_nop 1: a DPP source written by the previous VALU instruction needs
+// two wait states, which hipcc does not insert inside asm.)
+__device__ __forceinline__ float wave_amax_dpp(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }
 // 8 floats -> 8 e4m3 bytes (element j in byte j)
@@ -345,19 +346,19 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const char* src = rawb + (i & 1) * 2048 + olane() * 16;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
-    x_amax = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
-                   fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+    float m;                                             // four v_max3_f32 with |.| source modifiers
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v0[3]), "v"(v1[0]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v1[1]), "v"(v1[2]));
+    asm("v_max_f32 %0, %0, |%1|" : "+v"(m) : "v"(v1[3]));
+    x_amax = m;
   };
   auto x_quant2 = [&](int i) {
     const int l = olane();
     const char* src = rawb + (i & 1) * 2048 + l * 16;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
-#ifdef M3_F8_DBG_OLDMAX
-    const float amax = fmaxf(wave_max(x_amax), 1e-30f);
-#else
-    const float amax = fmaxf(wave_max_valu(x_amax), 1e-30f);
-#endif
+    const float amax = fmaxf(wave_amax_dpp(x_amax), 1e-30f);
     const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if ((l & 31) == i) sx_n = amax * (1.f / 448.f);
     int q0 = 0, q1 = 0;
