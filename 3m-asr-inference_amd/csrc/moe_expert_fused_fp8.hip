@@ -353,14 +353,18 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     asm("v_max_f32 %0, %0, |%1|" : "+v"(m) : "v"(v1[3]));
     x_amax = m;
   };
-  auto x_quant2 = [&](int i) {
+  float x_inv = 0.f;
+  auto x_quant2a = [&](int i) {                          // reduce over the wave, scale
+    const float amax = fmaxf(wave_amax_dpp(x_amax), 1e-30f);
+    x_inv = 448.f * __builtin_amdgcn_rcpf(amax);
+    if ((olane() & 31) == i) sx_n = amax * (1.f / 448.f);
+  };
+  auto x_quant2b = [&](int i) {                          // convert (saturating: MODE.FP16_OVFL) and store into the image
     const int l = olane();
     const char* src = rawb + (i & 1) * 2048 + l * 16;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
-    const float amax = fmaxf(wave_amax_dpp(x_amax), 1e-30f);
-    const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
-    if ((l & 31) == i) sx_n = amax * (1.f / 448.f);
+    const float inv = x_inv;
     int q0 = 0, q1 = 0;
     q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
     q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
@@ -371,7 +375,8 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   };
   auto x_quant = [&](int i) {
     x_quant1(i);
-    x_quant2(i);
+    x_quant2a(i);
+    x_quant2b(i);
   };
 
   // ---- weight staging through registers: wave wv brings KB 8 wv .. 8 wv + 7 of every 32-KB piece, natural (fully
@@ -423,98 +428,109 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     load_kb(w1e, w2e, abs_slice(0), 1, ii);            // piece 1 in flight
   }
 
-  long hq[2][2];                                       // Hq fragments of the current slice: [f block][k-step of the block]
+  int hq32[2][4];                                      // Hq of the current slice: [f block][dword = 4 e4m3 of registers 4 d .. 4 d + 3]
 
   auto lo64 = [](const u32x4& a) { return (long)(((unsigned long long)a[1] << 32) | a[0]); };
   auto hi64 = [](const u32x4& a) { return (long)(((unsigned long long)a[3] << 32) | a[2]); };
-  // SiLU + quantisation of a finished 32 x 32 block of z, a quarter (registers 4 q4 .. 4 q4 + 3 = f 32 fb + 16 h + 4 q4 ..)
-  // at a time: the quarters are issued between the MFMA batches of the NEXT block, so the VALU work runs in the MFMAs' shadow;
-  // two quarters make the 8 bytes of one k-step of GEMM-2's B operand
-  // Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction) and the H scale folded into the
-  // sigmoid's denominator: H / h_scale = z / ((1 + 2^(-z log2 e)) h_scale) -- the step is bound by VALU issue, not by MFMAs
-  float hv[8];
+  auto pack64 = [](int lo, int hi) { return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo); };
+
+  // ---- The step as 32 SLOTS of two MFMAs (64 cycles of the matrix pipe) each.  This wave is the only one on its SIMD and
+  //      issues in order: while an MFMA occupies the pipe, a second MFMA behind it blocks everything, an independent VALU /
+  //      LDS / memory instruction does not.  Left to itself hipcc groups 8-14 MFMAs and the other ~470 instructions of a step
+  //      into separate runs (measured: 75 k of the MFMAs' 131 k cycles per work-group not overlapped).  So every slot is
+  //      [fragment read for slot + 3][2 MFMAs][<= ~14 other instructions], fenced by sched_barrier:
+  //        slots 3, 7, .., 31   one KB of the weight stream (ds_write of piece t + 1, load of piece t + 2)
+  //        slots 1, 5, .., 29   the next tile's X (row A: wait + partial amax, reduce, convert, next fill; row B the same)
+  //        even slots           SiLU + quantisation of two z registers (GEMM-1: block 0 in the second half; GEMM-2: block 1
+  //                             in the first half)
+  // SiLU in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction) with the H scale folded into the
+  // sigmoid's denominator: H / h_scale = z / ((1 + 2^(-z log2 e)) h_scale); b1 / s1 of a pair are fetched one pair ahead.
   const f32x2 hs2 = {h_scale, h_scale};
-  auto silu_quarter = [&](const f32x16& acc, int sl_rel, int fb, int q4) {
-    const int fo = sl_rel * 64 + fb * 32 + 16 * (olane() >> 5) + 4 * q4;
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1_lds + fo);
-    const f32x4 ss = *reinterpret_cast<const f32x4*>(s1_lds + fo);
-    const f32x2 sx2 = {sx, sx};
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f32x2 a2 = {acc[4 * q4 + 2 * p], acc[4 * q4 + 2 * p + 1]};
-      const f32x2 sc = f32x2{ss[2 * p], ss[2 * p + 1]} * sx2;
-      const f32x2 z = __builtin_elementwise_fma(a2, sc, f32x2{bb[2 * p], bb[2 * p + 1]});
-      const f32x2 t = z * f32x2{-1.44269504088896f, -1.44269504088896f};
-      const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      const f32x2 d = __builtin_elementwise_fma(e, hs2, hs2);
-      const f32x2 hh = z * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-      hv[4 * (q4 & 1) + 2 * p] = hh[0];
-      hv[4 * (q4 & 1) + 2 * p + 1] = hh[1];
-    }
-    if (q4 & 1) hq[fb][q4 >> 1] = q8s(hv);
+  f32x2 bb_c, ss_c;
+  auto bias_fetch = [&](int sl_rel, int fb, int p) {
+    const int fo = sl_rel * 64 + fb * 32 + 16 * (olane() >> 5) + 2 * p;
+    bb_c = *reinterpret_cast<const f32x2*>(b1_lds + fo);
+    ss_c = *reinterpret_cast<const f32x2*>(s1_lds + fo);
   };
-  f32x16 acc_a, acc_b;                                 // z blocks fb = 0 / 1 of the current slice
-  // fragment reads run two batches of 2 (8 VGPRs each, 4 k-steps) ahead of the MFMAs that consume them (ring of three)
-  auto chain1 = [&](const char* blk, f32x16& acc, auto&& between) {
+  auto silu_pair = [&](const f32x16& acc, int fb, int p, int sl_rel_n, int fb_n, int p_n) {
+#ifdef M3_F8_ABL_NO_SILU   // ablation builds (diagnostics; results are garbage)
+    hq32[fb][p >> 1] = __builtin_bit_cast(int, acc[2 * p]);
+    return;
+#endif
+    const f32x2 bb = bb_c, ss = ss_c;
+    bias_fetch(sl_rel_n, fb_n, p_n);
+    const f32x2 a2 = {acc[2 * p], acc[2 * p + 1]};
+    const f32x2 sc = ss * f32x2{sx, sx};
+    const f32x2 z = __builtin_elementwise_fma(a2, sc, bb);
+    const f32x2 t = z * f32x2{-1.44269504088896f, -1.44269504088896f};
+    const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2 d = __builtin_elementwise_fma(e, hs2, hs2);
+    const f32x2 hh = z * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    // (saturating conversion: MODE.FP16_OVFL is set)
+    if (p & 1) hq32[fb][p >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(hh[0], hh[1], hq32[fb][p >> 1], true);
+    else hq32[fb][p >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(hh[0], hh[1], 0, false);
+    asm volatile("" : "+v"(hq32[fb][p >> 1]));          // (pins the pair to its slot: hipcc otherwise sinks the transcendentals
+  };                                                    //  of all pairs to the end of the step, where nothing overlaps them)
+  f32x16 acc_a, acc_b;                                 // z blocks fb = 0 / 1 of the current slice (arch VGPRs: asm MFMAs)
+  // fragment read addresses: W1 block fb, step pair m: byte fb * 32 * 528 + r * 528 + 16 h + 32 m (padded rows: no swizzle)
+  //                          W2 block db, step pair m: byte db * 2048 + (rd2 ^ (m << 5)), rd2 = (r << 6) | ((h ^ ((r >> 2) & 3)) << 4)
+  // step q = 0 of a slice: slots 0..15 z block 0, slots 16..31 z block 1
+  auto gemm1 = [&](const char* slot, auto&& work) {
     const int l = olane();
-    const char* rp = blk + (l & 31) * kW1Row + (l >> 5) * 16;
-    u32x4 a[3][2];
+    const char* rp = slot + (l & 31) * kW1Row + (l >> 5) * 16;
+    auto frag = [&](int s) -> u32x4 {
+#ifdef M3_F8_ABL_NO_READS
+      u32x4 v = {1u, 2u, 3u, 4u};
+      asm volatile("" : "+v"(v));
+      return v;
+#else
+      return *reinterpret_cast<const u32x4*>(rp + (s >> 4) * (32 * kW1Row) + (s & 15) * 32);
+#endif
+    };
+    u32x4 fr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j >> 1][j & 1] = *reinterpret_cast<const u32x4*>(rp + j * 32);
+    for (int s = 0; s < 3; ++s) fr[s] = frag(s);
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-      if (bb + 2 < 8) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          a[(bb + 2) % 3][j] = *reinterpret_cast<const u32x4*>(rp + (2 * bb + 4 + j) * 32);
+    for (int s = 0; s < 32; ++s) {
+      if (s + 3 < 32) fr[(s + 3) & 3] = frag(s + 3);
+      const int m = s & 15;
+      if (s < 16) {
+        if (m == 0) mfma8_v0(acc_a, lo64(fr[s & 3]), xq[0]);
+        else mfma8_v(acc_a, lo64(fr[s & 3]), xq[2 * m]);
+        mfma8_v(acc_a, hi64(fr[s & 3]), xq[2 * m + 1]);
+      } else {
+        if (m == 0) mfma8_v0(acc_b, lo64(fr[s & 3]), xq[0]);
+        else mfma8_v(acc_b, lo64(fr[s & 3]), xq[2 * m]);
+        mfma8_v(acc_b, hi64(fr[s & 3]), xq[2 * m + 1]);
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = 2 * bb + j;
-        if (m == 0) mfma8_v0(acc, lo64(a[bb % 3][j]), xq[0]);
-        else mfma8_v(acc, lo64(a[bb % 3][j]), xq[2 * m]);
-        mfma8_v(acc, hi64(a[bb % 3][j]), xq[2 * m + 1]);
-      }
-      if (bb & 1) between(bb >> 1);
+      work(s);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    mfma8_v_settle(acc);
   };
-  // step q = 0 of a slice: z block 0, then z block 1 with SiLU(block 0) in its shadow; SiLU(block 1) runs in GEMM-2's shadow
-  auto gemm1 = [&](const char* slot, int sl_rel, auto&& service) {
-    chain1(slot, acc_a, [&](int b) { service(b); });
-    chain1(slot + 32 * kW1Row, acc_b, [&](int b) {
-      silu_quarter(acc_a, sl_rel, 0, b);
-      service(4 + b);
-    });
-  };
-  // step q = 1: pass A multiplies the f block 0 half of W2 (k-steps 0, 1) into all 16 output blocks while SiLU(block 1)
-  // is computed, pass B the f block 1 half
-  auto gemm2 = [&](const char* slot, int sl_rel, auto&& service) {
+  // step q = 1: slots 0..15 multiply the f block 0 half of W2 into the 16 output blocks, slots 16..31 the f block 1 half
+  auto gemm2 = [&](const char* slot, auto&& work) {
     const int l = olane();
     const int rb = ((l & 31) << 6) | (((l >> 5) ^ ((l >> 2) & 3)) << 4);
+    auto frag = [&](int s) -> u32x4 {
+#ifdef M3_F8_ABL_NO_READS
+      u32x4 v = {1u, 2u, 3u, 4u};
+      asm volatile("" : "+v"(v));
+      return v;
+#else
+      return *reinterpret_cast<const u32x4*>(slot + (s & 15) * 2048 + (rb ^ ((s >> 4) << 5)));
+#endif
+    };
+    u32x4 fr[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      u32x4 a[3][2];                                    // a batch = two output blocks
+    for (int s = 0; s < 3; ++s) fr[s] = frag(s);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[k >> 1][k & 1] = *reinterpret_cast<const u32x4*>(slot + k * 2048 + (rb ^ (m << 5)));
-#pragma unroll
-      for (int bb = 0; bb < 8; ++bb) {
-        if (bb + 2 < 8) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            a[(bb + 2) % 3][k] = *reinterpret_cast<const u32x4*>(slot + (2 * bb + 4 + k) * 2048 + (rb ^ (m << 5)));
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int db = 2 * bb + k;
-          accy[db] = mfma8(lo64(a[bb % 3][k]), hq[m][0], accy[db]);
-          accy[db] = mfma8(hi64(a[bb % 3][k]), hq[m][1], accy[db]);
-        }
-        if (bb & 1) {
-          if (m == 0) silu_quarter(acc_b, sl_rel, 1, bb >> 1);
-          service(4 * m + (bb >> 1));
-        }
-      }
+    for (int s = 0; s < 32; ++s) {
+      if (s + 3 < 32) fr[(s + 3) & 3] = frag(s + 3);
+      const int m = s >> 4, db = s & 15;
+      accy[db] = mfma8(lo64(fr[s & 3]), pack64(hq32[m][0], hq32[m][1]), accy[db]);
+      accy[db] = mfma8(hi64(fr[s & 3]), pack64(hq32[m][2], hq32[m][3]), accy[db]);
+      work(s);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -557,42 +573,51 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
         M3_DIAG(const unsigned long long c0 = __builtin_amdgcn_s_memtime();)
         __syncthreads();
         M3_DIAG(const unsigned long long c1 = __builtin_amdgcn_s_memtime();)
-        const bool xq_step = has_next && t >= 1 && t <= 16, xi_step = has_next && t < 16;
-        auto service = [&](int ii) {
-          // vmcnt arithmetic: every service issues exactly one load; row A's fills are issued after load 1,
-          // row B's after load 5 -> 8 VMEM operations are younger than a row's fills when it is quantised a step later
-          // (6 for row B at t = 16, when no further fills follow)
-#ifdef M3_F8_DBG_UNSPLIT
-          if (xq_step && ii == 0) {
-            wait_vmcnt<8>();
-            x_quant(2 * (t - 1));
-          }
-          if (xq_step && ii == 4) {
-            if (t == 16) wait_vmcnt<6>(); else wait_vmcnt<8>();
-            x_quant(2 * (t - 1) + 1);
-          }
+#ifdef M3_F8_ABL_NO_XPF
+        const bool xq_step = false, xi_step = false;
 #else
-          if (xq_step && ii == 0) {
-            wait_vmcnt<8>();
-            x_quant1(2 * (t - 1));
-          }
-          if (xq_step && ii == 1) x_quant2(2 * (t - 1));  // (before this service's fill of the same raw row: x_issue waits lgkmcnt)
-          if (xq_step && ii == 4) {
-            if (t == 16) wait_vmcnt<6>(); else wait_vmcnt<8>();
-            x_quant1(2 * (t - 1) + 1);
-          }
-          if (xq_step && ii == 5) x_quant2(2 * (t - 1) + 1);
+        const bool xq_step = has_next && t >= 1 && t <= 16, xi_step = has_next && t < 16;
 #endif
-          // (unconditional: past the work-group's last piece the stream re-loads that tile's first pieces into slots nobody
-          //  reads any more -- straight-line code keeps hipcc's vmcnt arithmetic exact)
-          store_kb(q ^ 1, q ^ 1, ii);                  // piece t + 1 has the other q and the other slot
-          load_kb(wa, wb, sl_next, q, ii);
-          if (xi_step && ii == 1) x_issue(2 * t);
-          if (xi_step && ii == 5) x_issue(2 * t + 1);
+        // vmcnt arithmetic of the X prefetch: a step issues its 8 weight loads in slots 3, 7, .., 31, row A's two fills in slot
+        // 13 and row B's in slot 29; row A is first read in slot 1 of the next step (younger: 5 loads + 2 fills = 7), row B in
+        // slot 17 (1 + 4 loads + row A's 2 new fills = 7, or 5 at t = 16 when no further fills follow)
+        const int sl_rel = abs_slice(sl) - sl0, sl_rel_next = last_sl ? 0 : abs_slice(sl + 1) - sl0;
+        auto work = [&](int s) {
+          if ((s & 3) == 3) {
+#ifndef M3_F8_ABL_NO_STAGE
+            // (unconditional: past the work-group's last piece the stream re-loads that tile's first pieces into slots
+            //  nobody reads any more -- straight-line code keeps hipcc's vmcnt arithmetic exact)
+            store_kb(q ^ 1, q ^ 1, s >> 2);            // piece t + 1 has the other q and the other slot
+            load_kb(wa, wb, sl_next, q, s >> 2);
+#endif
+          } else if (s & 1) {
+            const int row = 2 * (t - 1) + (s >> 4);    // the row that arrived during the previous step
+            switch ((s >> 2) & 3) {
+              case 0:
+                if (xq_step) {
+                  if (s < 16 || t < 16) wait_vmcnt<7>(); else wait_vmcnt<5>();
+                  x_quant1(row);
+                }
+                break;
+              case 1: if (xq_step) x_quant2a(row); break;
+              case 2: if (xq_step) x_quant2b(row); break;
+              default: if (xi_step) x_issue(2 * t + (s >> 4)); break;
+            }
+          } else if (q == 0 && s >= 16) {
+            const int p = (s - 16) >> 1;
+            silu_pair(acc_a, 0, p, sl_rel, p < 7 ? 0 : 1, p < 7 ? p + 1 : 0);
+          } else if (q == 1 && s < 16) {
+            const int p = s >> 1;
+            silu_pair(acc_b, 1, p, p < 7 ? sl_rel : sl_rel_next, p < 7 ? 1 : 0, p < 7 ? p + 1 : 0);
+          }
         };
         const char* slot = smem + q * kSlot;
-        if (q == 0) gemm1(slot, abs_slice(sl) - sl0, service);
-        else gemm2(slot, abs_slice(sl) - sl0, service);
+        if (q == 0) {
+          if (sl == 0) bias_fetch(sl_rel, 0, 0);       // (behind the barrier that makes this tile's b1 / s1 visible)
+          gemm1(slot, work);
+        } else {
+          gemm2(slot, work);
+        }
         M3_DIAG(asm volatile("s_nop 0" ::: "memory"); const unsigned long long c4 = __builtin_amdgcn_s_memtime();
                 dg[0] += c1 - c0; if (q == 0) dg[3] += c4 - c1; else dg[4] += c4 - c1;)
       }
