@@ -79,6 +79,9 @@ def parse():
                          "292 kernels; measured 2-3 %% slower than the staged path, so off by default)")
     ap.add_argument("--weight-dtype", choices=["f32", "bf16", "fp8"], default="f32",
                     help="storage of the GEMM weights (bf16 = BASELINE.json configs[2]; the headline metric is f32)")
+    ap.add_argument("--fp8-activations", action="store_true",
+                    help="with --weight-dtype fp8: fp8 ARITHMETIC in the grouped expert FFN (e4m3 activations, fp8 MFMA); the "
+                         "per-layer H scales are calibrated on the benchmark batch before timing (m3asr.calibrate)")
     ap.add_argument("--varlen", default="", help="LO-HI: utterance lengths drawn from U[LO,HI] frames (configs[2]: 50-500)")
     ap.add_argument("--profile-stages", action="store_true", help="print per-stage HIP-event times to stderr")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -256,7 +259,10 @@ def main():
     from m3asr.weights import make_weights
 
     # host-side work first (weights are generated on the CPU), the device is touched afterwards
-    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts, weight_dtype=args.weight_dtype)
+    if args.fp8_activations and args.weight_dtype != "fp8":
+        raise SystemExit("--fp8-activations needs --weight-dtype fp8")
+    cfg = EncoderConfig(num_blocks=args.layers, num_experts=args.experts, weight_dtype=args.weight_dtype,
+                        fp8_activations=bool(args.fp8_activations))
     weights = make_weights(cfg, seed=0)
     phase("weights generated on the host")
     torch.cuda.set_device(local_rank)
@@ -318,6 +324,14 @@ def main():
         balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
         phase("synthetic routers calibrated")
     route = {"staged": 0, "fused": 1, "split": 2}[args.route_mode] if args.route_mode else (1 if args.fuse_route else 0)
+    if args.fp8_activations:                 # static H scale per MoE layer, from this batch (untimed set-up, like a builder run)
+        from m3asr.calibrate import calibrate_h_scales
+        del eng
+        torch.cuda.empty_cache()
+        h_scales = calibrate_h_scales(cfg, weights, [(feat, feat_len)], device=dev)
+        torch.cuda.empty_cache()
+        phase("H scales calibrated (%.3g .. %.3g)" % (min(h_scales), max(h_scales)))
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=0, packed_rows=packed)
     if route:                                # rebuild from the calibrated state_dict
         del eng
         torch.cuda.empty_cache()
