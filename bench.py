@@ -324,6 +324,7 @@ def main():
         balance_router(eng, weights)         # updates the device weights in place and the CPU state_dict
         phase("synthetic routers calibrated")
     route = {"staged": 0, "fused": 1, "split": 2}[args.route_mode] if args.route_mode else (1 if args.fuse_route else 0)
+    fp8_h_scales = None
     if args.fp8_activations:                 # static H scale per MoE layer, from this batch (untimed set-up, like a builder run)
         from m3asr.calibrate import calibrate_h_scales
         del eng
@@ -331,6 +332,7 @@ def main():
         h_scales = calibrate_h_scales(cfg, weights, [(feat, feat_len)], device=dev)
         torch.cuda.empty_cache()
         phase("H scales calibrated (%.3g .. %.3g)" % (min(h_scales), max(h_scales)))
+        fp8_h_scales = [round(float(min(h_scales)), 6), round(float(max(h_scales)), 6)]
         eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=0, packed_rows=packed)
     if route:                                # rebuild from the calibrated state_dict
         del eng
@@ -587,7 +589,7 @@ def main():
                                       "weights); one request alone: latency_ms_one_stream" % (len(ctxs), B),
                           "latency_ms_one_stream": round(latency_ms, 4),
                           "frames_per_s_one_stream": round(n_frames / (latency_ms * 1e-3), 1), "hip_graph": use_graph,
-                          "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
+                          "h_scale_min_max": fp8_h_scales, "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
                           "routing": args.routing, "route_mode": ["staged", "fused", "split"][route],
                           "packed_rows": bool(B > 1 and eng.packed_rows())},
                "roofline": roofline, "roofline_expert": roofline_expert, "forward": forward, "cpu_baseline": cpu}
