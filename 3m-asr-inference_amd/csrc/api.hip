@@ -141,6 +141,13 @@ int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_
   return launch_moe_combine(rows, 1, mapping, nullptr, gate_value, nullptr, resid, alpha, ln_gamma, ln_beta, ln_eps, out,
                             S, idim, (hipStream_t)stream);
 }
+int m3_moe_combine_bf16(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid, float alpha,
+                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, void* out_bf16, int S, int idim,
+                        m3_stream stream) {
+  M3_REQUIRE(rows && mapping && out, "moe_combine_bf16: null pointer");
+  return launch_moe_combine(rows, 1, mapping, nullptr, gate_value, nullptr, resid, alpha, ln_gamma, ln_beta, ln_eps, out,
+                            S, idim, (hipStream_t)stream, out_bf16);
+}
 int m3_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_histogram, int S, int world, int e_loc,
                    int capacity, int32_t* map_send, void* wire, int row_bytes, m3_stream stream) {
   M3_REQUIRE(gate_idx && mapping && acc_histogram && map_send && wire, "ep_send_map: null pointer");

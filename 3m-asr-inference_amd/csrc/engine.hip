@@ -740,10 +740,10 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
   {
     // bf16 activation operands need every GEMM that reads or rewrites them on the LDS-tiled kernel: the narrowest ones
-    // are the D x D projections; the expert-parallel driver replaces the combine stage with its own op (no bf16 copy)
+    // are the D x D projections (the expert-parallel driver's combine op writes the bf16 copy too: m3_moe_combine_bf16)
     GemmParams t;
     t.M = B * Tp; t.N = c.attention_dim; t.K = c.attention_dim; t.w_bf16 = 1;
-    e->cur.a16 = c.weight_dtype != M3_F32 && c.bf16_activations >= 0 && c.ep_world_size <= 1 && !c.debug_taps && c.embed_dim == c.attention_dim &&
+    e->cur.a16 = c.weight_dtype != M3_F32 && c.bf16_activations >= 0 && !c.debug_taps && c.embed_dim == c.attention_dim &&
                  (c.embed_linear_units % 128) == 0 && (c.hidden_units % 128) == 0 && gemm_bf16w_uses_tiled(t);
   }
   e->cur.packed = use_packed_rows(c, B);

@@ -79,8 +79,8 @@ class HipBackend:
         return self.ops.moe_expert_ffn(rows, gate_local, w["w1"], w["b1"], w["w2"], w["b2"],
                                        w1_scale=w.get("s1"), w2_scale=w.get("s2"), out=out, workspace=workspace)
 
-    def combine(self, rows, mapping, gate_value, resid, alpha, ln, out=None):
-        return self.ops.moe_combine(rows, mapping, gate_value, resid, alpha, ln, out=out)
+    def combine(self, rows, mapping, gate_value, resid, alpha, ln, out=None, out_bf16=None):
+        return self.ops.moe_combine(rows, mapping, gate_value, resid, alpha, ln, out=out, out_bf16=out_bf16)
 
 
 class EpBuffers:
@@ -110,12 +110,13 @@ def agree_capacity(S, device, group=None):
 
 
 def ep_moe_layer(x, gate_idx, gate_value, weights, e_loc, resid=None, alpha=1.0, ln=None, out=None, backend=None,
-                 group=None, buffers=None):
+                 group=None, buffers=None, out_bf16=None):
     """One expert-parallel MoE feed-forward on this rank's tokens; only enqueues work (no host read-back).
 
     x (S,D) f32: LayerNorm'd MoE input; gate_idx (S,) i32 GLOBAL expert id or -1; gate_value (S,) f32 or None;
     weights {"w1","b1","w2","b2"}: THIS rank's experts [E_loc,...]; returns LN(resid + alpha*gate*expert(x)) (S,D).
     buffers: EpBuffers of this shape (created on the fly when None -- that path costs one capacity all-reduce).
+    out_bf16 (S,D) bf16: also receives the result (engines with bf16 activation operands keep such a copy of x).
     """
     be = backend if backend is not None else HipBackend()
     world = _world(group)
@@ -136,6 +137,8 @@ def ep_moe_layer(x, gate_idx, gate_value, weights, e_loc, resid=None, alpha=1.0,
     be.expert_ffn(rows, bf.gate_recv, weights, out=bf.wire_a.view(-1, D), workspace=bf.workspace)
     # global_gather, then local_gather + gate + residual + LayerNorm: token s reads wire row map_send[s]
     _all_to_all_equal(bf.wire_b, bf.wire_a, group)
+    if out_bf16 is not None:
+        return be.combine(bf.wire_b.view(-1, D), bf.map_send, gate_value, resid, alpha, ln, out, out_bf16=out_bf16)
     return be.combine(bf.wire_b.view(-1, D), bf.map_send, gate_value, resid, alpha, ln, out)
 
 
@@ -174,12 +177,10 @@ class ExpertParallelEncoder:
         names = eng.stage_names()
         if "blocks.0.moe_router" not in names or "router_e_all" in names:   # fused / split route engines never write xn
             raise RuntimeError("ExpertParallelEncoder needs an engine built with fuse_route=False (or ep_world_size > 1)")
-        try:
-            eng.buffer("xb")
-            raise RuntimeError("ExpertParallelEncoder needs an engine built with bf16_activations=False "
-                               "(the driver replaces the combine stage, which maintains the bf16 copy of x)")
+        try:       # engines with bf16 activation operands keep a bf16 copy of x: the driver's combine maintains it
+            self._xb = eng.buffer("xb", torch.bfloat16)
         except _lib.M3Error:
-            pass
+            self._xb = None
         S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
         key = (tuple(feat.shape), S)
         if key not in self._buffers:
@@ -209,7 +210,8 @@ class ExpertParallelEncoder:
                 gval = None if cfg.keep_expert_output else eng.buffer("blocks.%d.gate_value" % i)
                 L = self.layers[i]
                 ep_moe_layer(xn, gidx, gval, L["w"], self.e_loc, resid=x, alpha=0.5, ln=L["ln"], out=x,
-                             backend=self.backend, group=self.group, buffers=bufs)
+                             backend=self.backend, group=self.group, buffers=bufs,
+                             out_bf16=None if self._xb is None else self._xb.view(-1)[:S * D].view(S, D))
             eng.run_stages(*self._tail)
         return logits
 

@@ -125,12 +125,19 @@ def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alp
     return y
 
 
-def moe_combine(rows, mapping, gate_value=None, resid=None, alpha=1.0, ln=None, out=None):
-    """out[s] = LN(resid[s] + alpha * gate[s] * rows[mapping[s]]); rows are in scattered (expert-sorted) order."""
+def moe_combine(rows, mapping, gate_value=None, resid=None, alpha=1.0, ln=None, out=None, out_bf16=None):
+    """out[s] = LN(resid[s] + alpha * gate[s] * rows[mapping[s]]); rows are in scattered (expert-sorted) order.
+    out_bf16 (optional, (S, D) bf16): also receives the result rounded to bf16 (the engine's "xb" copy)."""
     lib = _lib.load()
     S, D = mapping.numel(), rows.shape[-1]
     y = out if out is not None else torch.empty(S, D, dtype=torch.float32, device=rows.device)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
+    if out_bf16 is not None:
+        assert out_bf16.dtype == torch.bfloat16 and out_bf16.numel() >= S * D and out_bf16.is_contiguous()
+        check(lib.m3_moe_combine_bf16(_f32(rows), _i32(mapping), _f32(gate_value.reshape(-1) if gate_value is not None else None),
+                                      _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), _p(out_bf16), S, D, _stream()),
+              "m3_moe_combine_bf16")
+        return y
     check(lib.m3_moe_combine(_f32(rows), _i32(mapping), _f32(gate_value.reshape(-1) if gate_value is not None else None),
                              _f32(resid), float(alpha), _f32(g), _f32(b), float(eps), _p(y), S, D, _stream()),
           "m3_moe_combine")

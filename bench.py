@@ -190,7 +190,7 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
                 dist.broadcast(t, src=0)
                 weights_full[k] = t.cpu()
     cfg = EncoderConfig(num_blocks=L, num_experts=E // world, ep_world_size=world, ep_rank=rank, weight_dtype=wdt)
-    eng = Engine.from_state_dict(cfg, weights_full, device=dev, bf16_activations=False)
+    eng = Engine.from_state_dict(cfg, weights_full, device=dev)
     ep = ExpertParallelEncoder(eng)
     ep.bind(feat, feat_len)
 

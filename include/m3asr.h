@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 5
+#define M3ASR_ABI_VERSION 6
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -150,6 +150,12 @@ int m3_moe_expert_ffn_fp8a8_active(int S, int num_expert, int idim, int hidden_u
 int m3_moe_combine(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid,
                    float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S,
                    int idim, m3_stream stream);
+/* The same, also writing the bf16 copy of `out` that engines with bf16 activation operands keep of the residual stream
+ * (engine buffer "xb"; out_bf16 = [S][idim] bf16, may be NULL): lets the expert-parallel driver stand in for the
+ * engine's own combine stage in the 16-bit modes. */
+int m3_moe_combine_bf16(const float* rows, const int32_t* mapping, const float* gate_value, const float* resid,
+                        float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out,
+                        void* out_bf16, int S, int idim, m3_stream stream);
 /* Expert-parallel exchange without a host round trip (replaces the host logic of FastMoE's moe_prepare_forward /
  * MOEScatter / MOEGather, trainer_3m_fix/fmoe/functions.py:13-52,63-86,175-199, which reads the counts back to size its
  * all-to-all-v).  The wire buffer has a FIXED shape [world][1 + capacity][row_bytes]: chunk j = what this rank sends to
