@@ -501,7 +501,8 @@ def main():
                     for r_ in (roofline, roofline_expert):
                         k_ = [v for k, v in ent["kernels"].items() if k.startswith(r_["kernel"].split("<")[0])]
                         if k_:
-                            r_["traffic"] = int(np.mean([v["traffic_bytes_per_launch"] for v in k_]))
+                            n_l_ = float(sum(v["launches"] for v in k_))      # launch-weighted over the family's template variants
+                            r_["traffic"] = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in k_) / max(n_l_, 1.0))
                             r_["traffic_source"] = "profiles/r02_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe)"
             except Exception:
                 pass
