@@ -6,7 +6,9 @@
  *     never copied or owned by an op (README.md:225); plain pointers and sizes only, no framework types;
  *   - `stream` is a hipStream_t passed as void*; ops only enqueue work on it (no host sync, no
  *     allocation -> every entry point is hipGraph-capturable), unlike the reference's FMoE enqueue
- *     which synchronises twice per layer (fmoe_expert_plugin.cpp:75-78,130);
+ *     which synchronises twice per layer (fmoe_expert_plugin.cpp:75-78,130).  One caveat: kernels that need more than
+ *     64 KB of LDS opt in with hipFuncSetAttribute the FIRST time their entry point runs in a process (not a stream
+ *     operation) -- call an entry point once outside a capture before capturing it; m3_engine_* does this at prepare;
  *   - return value: 0 = ok, non-zero = failure (reference: `int enqueue(...)`), message via
  *     m3_last_error() (reference only logs, common/common.h:26-38);
  *   - dtype codes 0/1/2 = the reference's HelperConfig.plugin_data_type (builder_helper.py:47-57).
