@@ -65,3 +65,33 @@ def test_batchnorm_fold_matches_eval_bn():
     got = F.conv1d(x, p[c + "depthwise_conv.weight_kc"].t().unsqueeze(1).contiguous(), p[c + "depthwise_conv.bias"],
                    padding=7, groups=cfg.attention_dim)
     assert torch.allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
+def test_fp8_plan_formats_and_calibration_entries(tmp_path):
+    """The 8-bit plan on the host side: e4m3 expert weights with one scale per output row (dequantised value within one
+    e4m3 step of the weight), bf16 dense GEMM weights, and -- in the fp8-ARITHMETIC mode -- one h_scale per MoE layer, taken
+    from the state dict when the calibrator put it there, else the documented default; all of it survives the plan file."""
+    import dataclasses
+    from m3asr.plan import DEFAULT_H_SCALE, quantize_fp8_rows
+    cfg = dataclasses.replace(EncoderConfig.tiny(), weight_dtype="fp8", fp8_activations=True)
+    w = make_weights(cfg, seed=5)
+    w["blocks.1.feed_forward.experts.h_scale"] = torch.tensor([0.0123])      # what m3asr.calibrate writes
+    p = pack_weights(w, cfg)
+    k1 = "blocks.0.feed_forward.experts.w_1."
+    assert p[k1 + "weight"].dtype == torch.float8_e4m3fn and p[k1 + "scale"].shape == w[k1 + "weight"].shape[:2]
+    deq = p[k1 + "weight"].float() * p[k1 + "scale"].unsqueeze(-1)
+    err = (deq - w[k1 + "weight"]).abs()
+    assert bool((err <= w[k1 + "weight"].abs() * 2.0 ** -4 + p[k1 + "scale"].unsqueeze(-1) * 2.0 ** -9 + 1e-12).all())   # 3 mantissa bits
+    assert p["blocks.0.self_attn.qkv.ln.weight"].dtype == torch.bfloat16                   # dense GEMM weights: bf16
+    assert p["blocks.0.feed_forward.router_weights_t"].dtype == torch.float32              # the router stays fp32
+    assert abs(float(p["blocks.0.feed_forward.experts.h_scale"]) - DEFAULT_H_SCALE) < 1e-8
+    assert abs(float(p["blocks.1.feed_forward.experts.h_scale"]) - 0.0123) < 1e-9
+    path = str(tmp_path / "tiny8.plan")
+    save_plan(path, cfg, p)
+    cfg2, p2, _ = load_plan(path)
+    assert cfg2 == cfg and cfg2.fp8_activations and list(p2) == list(p)
+    assert all(p[k].dtype == p2[k].dtype and torch.equal(p[k].view(torch.uint8) if p[k].dtype == torch.float8_e4m3fn else p[k],
+                                                         p2[k].view(torch.uint8) if p2[k].dtype == torch.float8_e4m3fn else p2[k]) for k in p)
+    # rows of zeros quantise to zeros with a finite scale
+    q, s = quantize_fp8_rows(torch.zeros(2, 3, 8), dims=(2,))
+    assert bool((q.float() == 0).all()) and bool(torch.isfinite(s).all())
