@@ -91,6 +91,7 @@ struct m3_engine {
     float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
+    int ep_cap = 0;        // expert parallel: rows per wire chunk this binding was built for (m3_engine_set_ep_capacity)
     // fold_pos_proj: linear_pos(pe[:T']) of every block, computed once per T'.  ENGINE-owned device memory (shared by all
     // bindings of the same T', freed with the last of them): a caller that reuses one workspace for several shapes, as a
     // TensorRT execution context does, must not be able to overwrite it between two forwards of a revived binding
@@ -101,14 +102,16 @@ struct m3_engine {
     hipGraphExec_t graph_exec = nullptr;
     bool graph_valid = false;
     uint64_t last_use = 0;
-    bool matches(int b, int t, const float* f, const int32_t* fl, const float* lg, const void* w, size_t wb) const {
-      return !stages.empty() && B == b && T == t && feat == f && feat_len == fl && logits == lg && ws == w && ws_bytes == wb;
+    bool matches(int b, int t, const float* f, const int32_t* fl, const float* lg, const void* w, size_t wb, int cap) const {
+      return !stages.empty() && B == b && T == t && feat == f && feat_len == fl && logits == lg && ws == w && ws_bytes == wb &&
+             ep_cap == cap;
     }
   };
   Bound cur;
   std::vector<Bound> parked;
   uint64_t use_clock = 0;
   int n_captures = 0;                                      // graphs captured so far (observability / tests)
+  int ep_capacity = 0;                                     // rows per wire chunk agreed by the ranks for the NEXT bindings (0 = own rows)
   std::unordered_map<int, std::weak_ptr<float>> pfold_by_tp;   // T' -> folded positional projection still in use
 };
 
@@ -251,6 +254,9 @@ struct Plan {
   float* pfold;                         // [n_blocks_total][Tp][D] when fold_pos_proj
   // packed ragged batches: row plan, padded staging of the subsamplers' output, packed logits
   int32_t *row0, *pad_of; float* xpad; void* xbpad; float* lpk;
+  // expert parallel (ep_world_size > 1): send-side index over GLOBAL expert ids, the two wire buffers [world][1 + C][D]
+  // and the receive-side gate; the MoE workspace is then sized for the world * (1 + C) rows a rank can receive
+  int32_t *ep_acc, *ep_mapping, *ep_pos, *ep_map_send, *ep_gate_recv; float *wire_a, *wire_b; int ep_cap, ep_rows;
   size_t bytes;
 };
 
@@ -260,7 +266,7 @@ bool use_packed_rows(const m3_engine_config& c, int B) {
   return !c.debug_taps && c.fuse_route == 0 && B <= 1024;   // (expert-parallel ranks too: rows past the live count never travel)
 }
 
-Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
+Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capacity = 0) {
   Plan p;
   Carver cv(base);
   const int Tp = sub_len(T), S = B * Tp;
@@ -286,8 +292,22 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T) {
   p.eall = cv.take<float>((size_t)S * Etot * c.num_blocks);
   p.gate_idx = cv.take<int32_t>((size_t)c.num_blocks * S);
   p.gate_val = cv.take<float>((size_t)c.num_blocks * S);
-  p.moe_ws_bytes = carve_moe_workspace(nullptr, S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
+  // rows per wire chunk: what the ranks agreed on (m3_engine_set_ep_capacity), at least this rank's own row count
+  const bool ep = world > 1 || c.ep_stages > 0;
+  p.ep_cap = ep ? (ep_capacity > S ? ep_capacity : S) : 0;
+  p.ep_rows = ep ? world * (p.ep_cap + 1) : 0;
+  p.moe_ws_bytes = carve_moe_workspace(nullptr, ep ? p.ep_rows : S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
   p.moe_ws = cv.take<char>(p.moe_ws_bytes * (size_t)(c.debug_taps ? c.num_blocks : 1));
+  p.ep_acc = p.ep_mapping = p.ep_pos = p.ep_map_send = p.ep_gate_recv = nullptr; p.wire_a = p.wire_b = nullptr;
+  if (ep) {
+    p.ep_acc = cv.take<int32_t>((size_t)Etot + 1);
+    p.ep_mapping = cv.take<int32_t>(S);
+    p.ep_pos = cv.take<int32_t>(S);
+    p.ep_map_send = cv.take<int32_t>(S);
+    p.ep_gate_recv = cv.take<int32_t>(p.ep_rows);
+    p.wire_a = cv.take<float>((size_t)p.ep_rows * c.attention_dim);
+    p.wire_b = cv.take<float>((size_t)p.ep_rows * c.attention_dim);
+  }
   {
     size_t n1 = 0, n2 = 0;
     if (c.weight_dtype == M3_F32) {
@@ -540,8 +560,71 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // out once as xn, the expert FFN's input
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
     add_gemm(e, pfx + "moe_router", r, true);
-    // "moe_local.*" stages are what the expert-parallel host driver replaces (m3asr/ep.py)
-    if (world == 1 && S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
+    const bool ep = world > 1 || c.ep_stages > 0;
+    if (ep) {
+      // ---- expert parallel (m3asr/ep.py drives the two all-to-alls between these stages; FastMoE semantics
+      //      trainer_3m_fix/fmoe/functions.py:13-86,175-199): nothing returns to the host, the exchange has a fixed shape
+      //      wire [world][1 + C][D]: chunk j = what goes to / came from rank j, header row = E_loc row counts ----
+      const int cap = pl.ep_cap, R = pl.ep_rows;
+      int32_t *g_acc = pl.ep_acc, *g_map = pl.ep_mapping, *g_pos = pl.ep_pos, *map_send = pl.ep_map_send, *gate_recv = pl.ep_gate_recv;
+      float *wire_a = pl.wire_a, *wire_b = pl.wire_b;
+      const MoeWorkspace rw = carve_moe_workspace(mws, R, E, D, F);     // receive side: R wire rows over the E local experts
+      // top-1 + local index over GLOBAL expert ids (the same kernel choice by row count as with all experts local)
+      const bool one_launch = S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
+      if (one_launch) {
+        add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
+          return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, g_map, g_acc, g_pos, s);
+        }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (Etot + 1), 0.0));
+      } else {
+        add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
+          return launch_softmax_top1(rl, Etot, live_len, live_rpb, S, Etot, gidx, gval, s);
+        }, stage_info("softmax_top1_kernel", 1, (double)S * (Etot * 4 + 8), 0.0));
+      }
+      // wire row of every token (+ count headers), rows scattered straight into the send wire
+      add_stage(e, pfx + "moe_ep.send", one_launch ? 2 : 3, [=](hipStream_t s) {
+        if (!one_launch)
+          if (int rc = launch_moe_index(gidx, S, Etot, g_map, g_acc, g_pos, s)) return rc;
+        if (int rc = launch_ep_send_map(gidx, g_map, g_acc, S, world, E, cap, map_send, wire_a, D * 4, s)) return rc;
+        return launch_local_scatter(xn, map_send, S, D * 4, wire_a, s);
+      }, stage_info("row_permute_kernel", one_launch ? 2 : 3, (double)S * D * 8 + 24.0 * S, 0.0));
+      if (world == 1) add_stage(e, pfx + "moe_ep.exchange1", 0, [=](hipStream_t s) {   // one rank: the all-to-all is a copy
+        M3_CHECK_HIP(hipMemcpyAsync(wire_b, wire_a, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+        return 0;
+      });
+      // this rank's experts on everything it received (its own stable index puts the rows in FastMoE's receive order: by
+      // local expert, then source rank, then wire order); results return to wire_a at the wire rows they came in on
+      const bool e16 = c.weight_dtype != M3_F32, e8 = c.weight_dtype == M3_FP8;
+      const float *es1 = w.es1, *es2 = w.es2;
+      const float h_scale = w.h_scale;
+      const int wmode = e8 ? (h_scale > 0.f ? 3 : 2) : (e16 ? 1 : 0);
+      const int elaunches = e16 ? expert_ffn_w16_launches(wmode, R, E, D, F) : (expert_ffn_f32_tiled(R, E, D, F) ? 2 : 1);
+      const float* erows = e16 ? expert_ffn_w16_rows(wmode, rw.slab, R, E, D, F) : expert_ffn_f32_rows(rw.slab, R, E, D, F);
+      const int eslices = e16 ? expert_ffn_w16_slices(wmode, R, E, D, F) : expert_ffn_f32_slices(R, E, D, F);
+      add_stage(e, pfx + "moe_ep.expert", 3 + elaunches, [=](hipStream_t s) {
+        if (int rc = launch_ep_recv_gate(wire_b, world, E, cap, D * 4, gate_recv, s)) return rc;
+        if (int rc = launch_moe_index(gate_recv, R, E, rw.mapping, rw.acc, rw.pos, s)) return rc;
+        int rc;
+        if (e8) rc = launch_expert_ffn_w8a8(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, rw.slab, s);
+        else if (e16) rc = launch_expert_ffn_bf16w(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, eb1, ew2, 1, rw.slab, s);
+        else rc = launch_expert_ffn_f32(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, eb1, ew2, 1, rw.slab, nullptr, nullptr, 0.f, s);
+        if (rc) return rc;
+        return launch_moe_combine(erows, eslices, rw.mapping, gate_recv, nullptr, eb2, nullptr, 1.f, nullptr, nullptr, 0.f, wire_a, R, D, s);
+      }, stage_info(e16 ? expert_ffn_w16_kernel(wmode, R, E, D, F)
+                        : (expert_ffn_f32_tiled(R, E, D, F) ? "expert_gemm_f32_tiled_kernel" : "expert_ffn_f32_kernel"),
+                    1, -1.0, 4.0 * D * F * S));
+      if (world == 1) add_stage(e, pfx + "moe_ep.exchange2", 0, [=](hipStream_t s) {
+        M3_CHECK_HIP(hipMemcpyAsync(wire_b, wire_a, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+        return 0;
+      });
+      // local_gather + gate + residual + LayerNorm: token s reads its result at the wire row it was sent from
+      add_stage(e, pfx + "moe_ep.combine", 1, [=](hipStream_t s) {
+        return launch_moe_combine(wire_b, 1, map_send, nullptr, gv, nullptr, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
+      }, stage_info("moe_combine_kernel", 1, (double)S * D * 12 + (a16 ? 2.0 * S * D : 0.0), (double)S * D * 11));
+      e->cur.buffers["ep.wire_a"] = Buf{wire_a, (size_t)R * D * 4};
+      e->cur.buffers["ep.wire_b"] = Buf{wire_b, (size_t)R * D * 4};
+    } else {
+    // "moe_local.*": index + grouped expert FFN + combine with all experts local
+    if (S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch (a single workgroup: right for a
       // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
@@ -568,6 +651,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
                       : (expert_ffn_f32_tiled(S, E, D, F) ? "expert_gemm_f32_tiled_kernel" : "expert_ffn_f32_kernel"),
                   1, -1.0, 4.0 * D * F * S));
     }
+    }
+    if (!(world > 1 || c.ep_stages > 0)) {
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
     const bool e16c = c.weight_dtype != M3_F32;
     const int wmode_c = c.weight_dtype == M3_FP8 ? (w.h_scale > 0.f ? 3 : 2) : 1;
@@ -576,6 +661,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
     }, stage_info("moe_combine_kernel", 1, (double)S * D * 4 * (eslices + 2) + (a16 ? 2.0 * S * D : 0.0), (double)S * D * (eslices + 10)));
+    }
     const std::string b = pfx.substr(0, pfx.size() - 1);
     e->cur.buffers[b + ".gate_idx"] = Buf{gidx, (size_t)S * 4};
     e->cur.buffers[b + ".gate_value"] = Buf{gval, (size_t)S * 4};
@@ -618,6 +704,8 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   if (c.weight_dtype == M3_FP8 && (c.attention_dim % 64 || c.hidden_units % 64))
     return fail("engine_create: fp8 experts need attention_dim and hidden_units that are multiples of 64");
   if (c.fp8_activations && c.weight_dtype != M3_FP8) return fail("engine_create: fp8_activations needs weight_dtype fp8");
+  if (c.ep_stages > 0 && c.fuse_route) return fail("engine_create: ep_stages needs the staged route (fuse_route = 0)");
+  if (c.ep_world_size > 1 && (c.ep_rank < 0 || c.ep_rank >= c.ep_world_size)) return fail("engine_create: ep_rank outside [0, ep_world_size)");
   if (c.weight_dtype != M3_F32) {
     if (c.fuse_route) return fail("engine_create: fuse_route is fp32-only");
     if (c.attention_dim % 32 || c.hidden_units % 64 || c.embed_linear_units % 32)
@@ -684,7 +772,7 @@ void m3_engine_destroy(m3_engine* engine) {
 
 size_t m3_engine_workspace_size(const m3_engine* engine, int B, int T) {
   if (!engine || B <= 0 || T < 7) return 0;
-  return make_plan(engine->cfg, nullptr, B, T).bytes;
+  return make_plan(engine->cfg, nullptr, B, T, engine->ep_capacity).bytes;
 }
 
 int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
@@ -700,13 +788,12 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_expert_ffn_w8_kernels()) return rc;
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
-  if (int rc = init_expert_ffn_fused_bf16_kernels()) return rc;
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
-  Plan pl = make_plan(c, workspace, B, T);
+  Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----
-  if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
+  if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity)) {
     e->cur.last_use = ++e->use_clock;
     return (int)e->cur.stages.size();
   }
@@ -727,7 +814,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     e->cur = m3_engine::Bound();
   }
   for (size_t i = 0; i < e->parked.size(); ++i)
-    if (e->parked[i].matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
+    if (e->parked[i].matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity)) {
       e->cur = std::move(e->parked[i]);
       e->parked.erase(e->parked.begin() + i);
       e->cur.last_use = ++e->use_clock;
@@ -736,6 +823,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.last_use = ++e->use_clock;
   e->cur.B = B; e->cur.T = T; e->cur.Tp = Tp; e->cur.S = B * Tp;
   e->cur.feat = feat; e->cur.feat_len = feat_len; e->cur.logits = logits; e->cur.ws = workspace; e->cur.ws_bytes = workspace_bytes;
+  e->cur.ep_cap = e->ep_capacity;
   e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false;
   e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
   {
@@ -841,9 +929,16 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (e->cur.a16) e->cur.buffers["xb"] = Buf{pl.xb, (size_t)S * D * 2};
   e->cur.buffers["lens"] = Buf{pl.lens, (size_t)B * 4};
   if (e->cur.packed) e->cur.buffers["row0"] = Buf{pl.row0, (size_t)(B + 1) * 4};
+  if (pl.ep_rows) e->cur.buffers["ep.gate_recv"] = Buf{pl.ep_gate_recv, (size_t)pl.ep_rows * 4};
   e->cur.buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 
   return (int)e->cur.stages.size();
+}
+
+int m3_engine_set_ep_capacity(m3_engine* engine, int rows_per_chunk) {
+  M3_REQUIRE(engine != nullptr && rows_per_chunk >= 0, "engine_set_ep_capacity: bad argument");
+  engine->ep_capacity = rows_per_chunk;
+  return 0;
 }
 
 int m3_engine_num_stages(const m3_engine* engine) { return engine ? (int)engine->cur.stages.size() : 0; }
@@ -882,11 +977,13 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
                       void* workspace, size_t workspace_bytes, int use_graph, m3_stream stream_) {
   M3_REQUIRE(e != nullptr, "engine_forward: null engine");
   hipStream_t stream = (hipStream_t)stream_;
-  if (!e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes)) {
+  if (!e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity)) {
     int rc = m3_engine_prepare(e, feat, feat_len, B, T, logits, workspace, workspace_bytes);
     if (rc < 0) return rc;
   }
   e->cur.last_use = ++e->use_clock;
+  M3_REQUIRE(e->cfg.ep_world_size <= 1, "engine_forward: an expert-parallel engine (ep_world_size = %d) is run stage-wise, with the "
+             "all-to-all between its moe_ep.* stages (m3asr/ep.py)", (int)e->cfg.ep_world_size);
   if (!use_graph) return m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
   if (!e->cur.graph_valid) {
     M3_REQUIRE(stream != nullptr, "engine_forward: graph capture needs a non-default stream");

@@ -115,13 +115,6 @@ float* expert_ffn_w16_rows(int wmode, float* slab, int S, int E, int D, int F);
 int expert_ffn_w16_slices(int wmode, int S, int E, int D, int F);
 int expert_ffn_w16_launches(int wmode, int S, int E, int D, int F);
 const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F);
-// bf16, long batches (D = 512): ONE kernel, H stays in registers (moe_expert_fused_bf16.hip); ybuf: fsplit x S x D fp32
-bool expert_ffn_fused_bf16_applies(int S, int E, int D, int F);
-int expert_ffn_fused_bf16_fsplit(int S, int E, int D, int F);
-int init_expert_ffn_fused_bf16_kernels();
-int launch_expert_ffn_fused_bf16(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
-                                 int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* ybuf,
-                                 hipStream_t stream);
 // fp8 arithmetic (e4m3 weights x e4m3 activations, fp8 MFMA), long batches (D = 512): moe_expert_fused_fp8.hip.
 // wmode 3 in the helpers above = "fp8 weights + fp8 activations where this kernel applies, else the weight-only form"
 bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F);

@@ -171,14 +171,12 @@ float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F) {   // what
 }
 int expert_ffn_bf16_slices(int S, int E, int D, int F) { return expert_ffn_bf16_tiled(S, E, D, F) ? 1 : F / kExpertSlice; }
 
-// bf16 weights take the fused one-kernel form where it applies (its result: fsplit slabs of sorted rows at the start of the
-// slab region); fp8 weights and everything else keep the layouts above
-static int w16_fsplit(int wmode, int S, int E, int D, int F) {
-  return wmode == 3 ? expert_ffn_fused_fp8_fsplit(S, E, D, F) : expert_ffn_fused_bf16_fsplit(S, E, D, F);
-}
+// fp8 arithmetic (wmode 3) takes the fused one-kernel form where it applies (its result: fsplit slabs of sorted rows at the
+// start of the slab region); bf16 and fp8 weight-only experts keep the layouts above
+static int w16_fsplit(int wmode, int S, int E, int D, int F) { return expert_ffn_fused_fp8_fsplit(S, E, D, F); }
 static bool w16_fused(int wmode, int S, int E, int D, int F) {
-  const bool applies = wmode == 1 ? expert_ffn_fused_bf16_applies(S, E, D, F) : (wmode == 3 && expert_ffn_fused_fp8_applies(S, E, D, F));
-  return applies && (size_t)w16_fsplit(wmode, S, E, D, F) * S * D * 4 <= expert_ffn_slab_bytes(S, D, F);
+  return wmode == 3 && expert_ffn_fused_fp8_applies(S, E, D, F) &&
+         (size_t)w16_fsplit(wmode, S, E, D, F) * S * D * 4 <= expert_ffn_slab_bytes(S, D, F);
 }
 bool expert_ffn_w8a8_fused(int S, int E, int D, int F) { return w16_fused(3, S, E, D, F); }
 float* expert_ffn_w16_rows(int wmode, float* slab, int S, int E, int D, int F) {
@@ -191,7 +189,7 @@ int expert_ffn_w16_launches(int wmode, int S, int E, int D, int F) {
   return w16_fused(wmode, S, E, D, F) ? 1 : (expert_ffn_bf16_tiled(S, E, D, F) ? 2 : 1);
 }
 const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F) {
-  if (w16_fused(wmode, S, E, D, F)) return wmode == 3 ? "expert_ffn_fused_fp8_kernel" : "expert_ffn_fused_bf16_kernel";
+  if (w16_fused(wmode, S, E, D, F)) return "expert_ffn_fused_fp8_kernel";
   if (wmode == 3) wmode = 2;
   if (expert_ffn_bf16_tiled(S, E, D, F)) return wmode == 2 ? "gemm_bf16w_tiled_kernel<grouped,fp8>" : "gemm_bf16w_tiled_kernel<grouped>";
   return wmode == 2 ? "expert_ffn_w8_kernel" : "expert_ffn_bf16w_kernel";
@@ -212,8 +210,6 @@ int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const i
   M3_REQUIRE((D & 31) == 0 && D <= 2048, "expert_ffn_bf16w: idim=%d must be a multiple of 32 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_bf16w: ldx=%d must be a multiple of 4", ldx);
-  if (w16_fused(1, S, E, D, F))
-    return launch_expert_ffn_fused_bf16(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab, stream);
   if (expert_ffn_bf16_tiled(S, E, D, F))
     return launch_expert_ffn_bf16w_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
                                          expert_ffn_bf16_rows(slab, S, E, D, F), stream);

@@ -13,7 +13,7 @@
 //                              keep H inside [2^-9, 448] h_scale -- it does not set the precision)
 //   z = (W1q . Xq) s1[f] sx[tok] + b1[f];  H = SiLU(z);  Y = (W2q . Hq) s2[d] h_scale      (b2 etc.: moe_combine_kernel)
 //
-// Structure: the transposed, register-resident formulation of moe_expert_fused_bf16.hip (tokens on the MFMA column axis,
+// Structure: the transposed, register-resident formulation first built for bf16 in round 2 (tokens on the MFMA column axis,
 // weights as the A operand streamed through LDS, GEMM-1's accumulator re-used as GEMM-2's B operand).
 // What fp8 changes: X fragments take 64 VGPRs instead of 128 and weight fragments 2 instead of 4; a 64-wide slice of F is
 // 32 KB of W1 + 32 KB of W2, i.e. ONE 32-KB piece each: 64 MFMAs per barrier, half the L2 -> LDS bytes per FLOP.
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   int row_end = acc_hist[cur.e + 1];
   int tile_row0 = acc_hist[cur.e] + cur.tt * kTok + wv * 32;
   int sl0 = cur.fs * nsl;
-  int phase0 = (cur.tt * 5) % nsl;                     // de-phased walk over the slices (see moe_expert_fused_bf16.hip)
+  int phase0 = (cur.tt * 5) % nsl;                     // de-phased walk over the slices (co-resident tiles must not ask L2 for the same lines at the same moment)
   const unsigned char* w1e = w1 + (size_t)cur.e * F * kD;
   const unsigned char* w2e = w2 + (size_t)cur.e * F * kD;
   auto abs_slice = [&](int rel) { const int v = rel + phase0; return sl0 + (v >= nsl ? v - nsl : v); };
@@ -710,9 +710,12 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
 }
 
 // ---- host side ----
-static int fused8_min_rows() {
-  const char* e = getenv("M3_EXPERT_FUSED_FP8_MIN_ROWS");
-  return e ? atoi(e) : 4096;
+static int fused8_min_rows() {   // read once: the engine freezes the form (and the combine's slab layout) when a shape is bound
+  static const int v = [] {
+    const char* e = getenv("M3_EXPERT_FUSED_FP8_MIN_ROWS");
+    return e ? atoi(e) : 4096;
+  }();
+  return v;
 }
 int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F) {
   const int tiles = cdiv(S, kTok) + E / 2;

@@ -44,7 +44,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
         "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
-        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations")]
+        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
@@ -137,6 +137,7 @@ SIGNATURES = {
     "m3_engine_workspace_size": (_sz, [_vp, _i, _i]),
     "m3_engine_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "m3_engine_prepare": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz]),
+    "m3_engine_set_ep_capacity": (_i, [_vp, _i]),
     "m3_engine_num_captures": (_i, [_vp]),
     "m3_engine_num_stages": (_i, [_vp]),
     "m3_engine_stage_name": (_cp, [_vp, _i]),

@@ -29,7 +29,9 @@ def collect_h_amax(cfg, state_dict, feat, feat_len, device="cuda:0", engine=None
     expert with m3_linear.  Returns (list of floats, engine) -- pass the engine back in to reuse it for the next batch."""
     import dataclasses
     if engine is None:
-        c32 = dataclasses.replace(cfg, weight_dtype="f32", fp8_activations=False, ep_world_size=1, ep_rank=0)
+        # (an expert-parallel config names E_loc experts per rank: calibration runs with all of them local)
+        c32 = dataclasses.replace(cfg, weight_dtype="f32", fp8_activations=False, ep_world_size=1, ep_rank=0,
+                                  num_experts=cfg.num_experts * max(1, cfg.ep_world_size))
         engine = Engine.from_state_dict(c32, state_dict, device=device, fuse_route=False, packed_rows=False)
     eng = engine
     B = feat.shape[0]

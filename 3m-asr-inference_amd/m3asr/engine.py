@@ -19,7 +19,8 @@ from .plan import pack_weights
 _TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32: _lib.I32, torch.float8_e4m3fn: _lib.FP8}
 
 
-def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True, packed_rows=None):
+def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True, packed_rows=None,
+                   ep_stages=False):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -37,12 +38,13 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.weight_dtype = {"f32": _lib.F32, "bf16": _lib.BF16, "fp8": _lib.FP8}[cfg.weight_dtype]
     ec.packed_rows = 0 if packed_rows is None else (1 if packed_rows else -1)
     ec.fp8_activations = int(bool(getattr(cfg, "fp8_activations", False)) and cfg.weight_dtype == "fp8")
+    ec.ep_stages = int(bool(ep_stages))
     return ec
 
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
-                 fuse_route=False, bf16_activations=True, packed_rows=None, max_shapes=8):
+                 fuse_route=False, bf16_activations=True, packed_rows=None, max_shapes=8, ep_stages=False):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
@@ -52,7 +54,9 @@ class Engine:
         (automatic); False disables it (needed when stages are replaced from the host, e.g. ExpertParallelEncoder).
         fuse_route: 0 / False = staged route (router GEMM on cat([embed, x]) with a LayerNorm prologue that writes xn);
         1 / True = router + top-1 + index in one single-workgroup launch (S <= 256); 2 = split route (embed half of all
-        routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel)."""
+        routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel).
+        ep_stages: build the expert-parallel stage list ("blocks.N.moe_ep.*") although cfg.ep_world_size is 1 -- a one-rank
+        rehearsal of the exchange (m3asr/ep.py); cfg.ep_world_size > 1 always builds it."""
         self.lib = _lib.load()
         from .plan import EXPERT_SLICE
         assert self.lib.m3_moe_expert_slice() == EXPERT_SLICE, "plan.EXPERT_SLICE out of sync with libm3asr_hip.so"
@@ -68,7 +72,9 @@ class Engine:
             table[i].data = self.weights[n].data_ptr()
             table[i].numel = self.weights[n].numel()
             table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
-        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if cfg.ep_world_size <= 1 else 0, bf16_activations, packed_rows)
+        self.ep_stages = bool(ep_stages) or cfg.ep_world_size > 1
+        ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if not self.ep_stages else 0, bf16_activations, packed_rows,
+                            ep_stages=ep_stages)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())
@@ -81,6 +87,12 @@ class Engine:
         self._ws = collections.OrderedDict()
         self._static = collections.OrderedDict()
         self._bound = None
+        self._ep_capacity = 0
+
+    def set_ep_capacity(self, rows_per_chunk):
+        """Expert parallel: rows per wire chunk for the bindings made from now on (the largest B*T' of any rank)."""
+        check(self.lib.m3_engine_set_ep_capacity(self.handle, int(rows_per_chunk)), "m3_engine_set_ep_capacity")
+        self._ep_capacity = int(rows_per_chunk)
 
     @classmethod
     def from_state_dict(cls, cfg, state_dict, **kw):
@@ -115,7 +127,8 @@ class Engine:
         return v
 
     def _workspace(self, B, T):
-        return self._lru(self._ws, (B, T), lambda: torch.empty(self.workspace_size(B, T), dtype=torch.uint8, device=self.device))
+        return self._lru(self._ws, (B, T, self._ep_capacity),
+                         lambda: torch.empty(self.workspace_size(B, T), dtype=torch.uint8, device=self.device))
 
     def bind(self, feat, feat_len, logits=None):
         """Bind device buffers (feat (B,T,idim) f32, feat_len (1,B)/(B,) i32); returns logits tensor."""

@@ -77,7 +77,8 @@ class HipBackend:
 
     def expert_ffn(self, rows, gate_local, w, out, workspace=None):
         return self.ops.moe_expert_ffn(rows, gate_local, w["w1"], w["b1"], w["w2"], w["b2"],
-                                       w1_scale=w.get("s1"), w2_scale=w.get("s2"), out=out, workspace=workspace)
+                                       w1_scale=w.get("s1"), w2_scale=w.get("s2"), out=out, workspace=workspace,
+                                       h_scale=w.get("h_scale"))
 
     def combine(self, rows, mapping, gate_value, resid, alpha, ln, out=None, out_bf16=None):
         return self.ops.moe_combine(rows, mapping, gate_value, resid, alpha, ln, out=out, out_bf16=out_bf16)
@@ -143,77 +144,113 @@ def ep_moe_layer(x, gate_idx, gate_value, weights, e_loc, resid=None, alpha=1.0,
 
 
 class ExpertParallelEncoder:
-    """Drives a staged native engine (m3asr.engine.Engine built with ep_world_size > 1) across ranks: every stage runs
-    on the engine's stream; the ``blocks.N.moe_local.*`` stages are replaced by ``ep_moe_layer``.  Works on padded and
-    on packed rows (rows past the live count carry gate_idx -1 and never travel)."""
+    """Drives an engine whose stage list holds the expert-parallel stages (m3asr.engine.Engine built with cfg.ep_world_size
+    > 1, or with ep_stages=True for a one-rank rehearsal): every kernel -- the exchange bookkeeping, the grouped expert FFN
+    on the received rows (plan layouts, fp8 arithmetic with the calibrated H scale included), the combine -- is a native
+    stage on the engine's stream; this class only puts the two all-to-alls of every MoE layer between them
+    (``blocks.N.moe_ep.send`` -> exchange -> ``.moe_ep.expert`` -> exchange -> ``.moe_ep.combine``).  Works on padded and on
+    packed rows (rows past the live count carry gate_idx -1 and never travel).
 
-    def __init__(self, engine, group=None):
+    graph=True: the whole forward -- native stages and collectives -- is captured once per binding into one graph on the
+    engine's stream and replayed (RCCL collectives are capturable; with one rank the engine's own hipGraph is used).  A
+    transport that stages through the host (gloo with device tensors) or a failed capture falls back to eager enqueueing;
+    ``self.graph_state`` says which ("engine graph" / "captured" / "eager: <reason>")."""
+
+    def __init__(self, engine, group=None, graph=True):
+        if not getattr(engine, "ep_stages", False):
+            raise RuntimeError("ExpertParallelEncoder needs an engine with the expert-parallel stages (cfg.ep_world_size > 1, or "
+                               "Engine(..., ep_stages=True) for a one-rank rehearsal)")
         self.eng, self.group = engine, group
-        # needs the staged route path (router GEMM materialises xn; gate / index / expert / combine are separate stages)
-        cfg = engine.cfg
-        self.e_loc = cfg.num_experts
-        self.backend = HipBackend()
-        self.layers = []
-        self._buffers = {}
-        for i in range(cfg.num_blocks):
-            p = "blocks.%d." % i
-            w = engine.weights
-            E, D, F = cfg.num_experts, cfg.attention_dim, cfg.hidden_units
-            # the plan keeps w_2 slice-major [E, F/S, D, S] for the fused engine; the C-ABI op takes the reference
-            # layout [E, D, F] -> undo once at set-up
-            w2 = w[p + "feed_forward.experts.w_2.weight_sliced"].permute(0, 2, 1, 3).reshape(E, D, F).contiguous()
-            wd = {"w1": w[p + "feed_forward.experts.w_1.weight"], "b1": w[p + "feed_forward.experts.w_1.bias"],
-                  "w2": w2, "b2": w[p + "feed_forward.experts.w_2.bias"]}
-            if (p + "feed_forward.experts.w_1.scale") in w:        # fp8 experts: per-row scales travel with the weights
-                wd["s1"], wd["s2"] = w[p + "feed_forward.experts.w_1.scale"], w[p + "feed_forward.experts.w_2.scale"]
-            self.layers.append({"w": wd,
-                                "ln": (w[p + "norm_final.weight"], w[p + "norm_final.bias"], 1e-12)})
+        self.world = _world(group)
+        if self.world != max(1, engine.cfg.ep_world_size):
+            raise RuntimeError("process group of %d ranks, engine built for ep_world_size=%d" % (self.world, engine.cfg.ep_world_size))
+        self.e_loc = engine.cfg.num_experts
+        self.want_graph = bool(graph)
+        self.graph_state = "eager: not bound"
+        self._graph = None
+        self._caps = {}
+
+    def on_host(self):
+        return self.world > 1 and dist.get_backend(self.group) == "gloo"
 
     def bind(self, feat, feat_len):
-        """Bind the input buffers, check the engine is usable and agree on the wire capacity (the only collective outside
-        the layers; once per shape)."""
+        """Bind the input buffers and agree on the wire capacity (the only collective outside the layers; once per shape)."""
         eng, cfg = self.eng, self.eng.cfg
+        B, T = int(feat.shape[0]), int(feat.shape[1])
+        S = B * eng.output_shape(B, T)[1]
+        key = (B, T)
+        if key not in self._caps:
+            self._caps[key] = agree_capacity(S, eng.device, self.group)
+        eng.set_ep_capacity(self._caps[key])
         logits = eng.bind(feat, feat_len)
         names = eng.stage_names()
-        if "blocks.0.moe_router" not in names or "router_e_all" in names:   # fused / split route engines never write xn
-            raise RuntimeError("ExpertParallelEncoder needs an engine built with fuse_route=False (or ep_world_size > 1)")
-        try:       # engines with bf16 activation operands keep a bf16 copy of x: the driver's combine maintains it
-            self._xb = eng.buffer("xb", torch.bfloat16)
-        except _lib.M3Error:
-            self._xb = None
-        S, D = eng.buffer("x").numel() // cfg.attention_dim, cfg.attention_dim
-        key = (tuple(feat.shape), S)
-        if key not in self._buffers:
-            cap = agree_capacity(S, eng.device, self.group)
-            self._buffers[key] = EpBuffers(S, D, _world(self.group), self.e_loc, cap, eng.device, F=cfg.hidden_units)
-        # per layer: (first replaced stage, stage after the last replaced one)
-        plan, cur = [], 0
-        for i in range(cfg.num_blocks):
-            # world == 1 engines fuse gate + index ("moe_gate_index", runs before): then only expert/combine are replaced
-            k = "blocks.%d.moe_local.index" % i
-            first = names.index(k) if k in names else names.index("blocks.%d.moe_local.expert" % i)
-            plan.append((cur, first))
-            cur = names.index("blocks.%d.moe_local.combine" % i) + 1
-        self._plan, self._tail, self._bound = plan, (cur, len(names)), (logits, S, D, self._buffers[key])
+        D = cfg.attention_dim
+        wa, wb = eng.buffer("ep.wire_a"), eng.buffer("ep.wire_b")
+        self._wire = (wa.view(self.world, -1, D), wb.view(self.world, -1, D))
+        # stage ranges between collectives: one rank -> the engine holds the exchanges itself (device copies)
+        cuts = []
+        if self.world > 1:
+            for i in range(cfg.num_blocks):
+                cuts.append(names.index("blocks.%d.moe_ep.send" % i) + 1)
+                cuts.append(names.index("blocks.%d.moe_ep.expert" % i) + 1)
+        self._segments = list(zip([0] + cuts, cuts + [len(names)]))
+        self._bound = (logits, S, D, self._caps[key])
+        self._graph = None
+        self.graph_state = "eager: not captured yet"
         return logits
 
-    def enqueue(self):
-        """Enqueue one forward on the engine's stream: native stages + exchange, no host synchronisation."""
-        eng, cfg = self.eng, self.eng.cfg
-        logits, S, D, bufs = self._bound
-        x = eng.buffer("x").view(S, D)
-        xn = eng.buffer("xn").view(S, D)
+    def _enqueue_eager(self):
+        eng = self.eng
+        wa, wb = self._wire
         with torch.cuda.stream(eng.stream):
-            for i, (a, b) in enumerate(self._plan):
+            for k, (a, b) in enumerate(self._segments):
                 eng.run_stages(a, b)
-                gidx = eng.buffer("blocks.%d.gate_idx" % i, torch.int32)
-                gval = None if cfg.keep_expert_output else eng.buffer("blocks.%d.gate_value" % i)
-                L = self.layers[i]
-                ep_moe_layer(xn, gidx, gval, L["w"], self.e_loc, resid=x, alpha=0.5, ln=L["ln"], out=x,
-                             backend=self.backend, group=self.group, buffers=bufs,
-                             out_bf16=None if self._xb is None else self._xb.view(-1)[:S * D].view(S, D))
-            eng.run_stages(*self._tail)
+                if k + 1 < len(self._segments):
+                    _all_to_all_equal(wb, wa, self.group)
+
+    def _capture(self):
+        """One graph for the whole forward.  Returns the reason it cannot be used, or None."""
+        eng = self.eng
+        if self.world == 1:
+            return None                                    # the native engine captures its own stage list (exchanges = copies)
+        if self.on_host():
+            return "the gloo transport stages device tensors through the host"
+        try:
+            eng.stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=eng.stream, capture_error_mode="thread_local"):
+                wa, wb = self._wire
+                for k, (a, b) in enumerate(self._segments):
+                    eng.run_stages(a, b)
+                    if k + 1 < len(self._segments):
+                        dist.all_to_all_single(wb, wa, group=self.group)
+            self._graph = g
+            return None
+        except Exception as ex:      # noqa: BLE001 -- a transport that cannot be captured still runs eagerly
+            self._graph = None
+            return "capture failed: %r" % (ex,)
+
+    def enqueue(self):
+        """Enqueue one forward on the engine's stream: native stages + exchanges, no host synchronisation on the RCCL
+        path (the gloo rehearsal stages every exchange through the host: 2 synchronisations per layer)."""
+        eng = self.eng
+        logits = self._bound[0]
+        if self.want_graph and self._graph is None and self.graph_state.startswith("eager: not captured"):
+            self._enqueue_eager()                           # first call of a binding runs eagerly (kernel attributes, RCCL set-up)
+            why = self._capture()
+            self.graph_state = ("engine graph" if self.world == 1 else "captured") if why is None else "eager: " + why
+            return logits
+        if self.want_graph and self.world == 1 and self.graph_state == "engine graph":
+            eng.forward(use_graph=True)
+        elif self._graph is not None:
+            with torch.cuda.stream(eng.stream):
+                self._graph.replay()
+        else:
+            self._enqueue_eager()
         return logits
+
+    def host_syncs_per_forward(self):
+        return 2 * self.eng.cfg.num_blocks if self.on_host() else 0
 
     def forward(self, feat, feat_len):
         b = getattr(self, "_bound_io", None)
@@ -222,4 +259,53 @@ class ExpertParallelEncoder:
             self._bound_io = (feat, feat_len)
         logits = self.enqueue()
         self.eng.stream.synchronize()
+        return logits
+
+
+class InProcessRanks:
+    """Rehearsal of an N-rank expert-parallel forward inside ONE process on ONE device: N engines (rank r built with
+    cfg.ep_world_size = N, cfg.ep_rank = r: its own expert shard, its own utterances, its own stream and workspace) are
+    stepped segment by segment and the all-to-all is performed by device copies between their wire buffers
+    (chunk j of rank i's send wire -> chunk i of rank j's receive wire: exactly what all_to_all_single with equal splits
+    does).  Every native stage, every wire format and the capacity agreement are the real ones; only the transport is
+    replaced.  Used to check an 8-rank configuration at real dimensions on a box with one GPU (a GPU box admits few
+    processes per device, and RCCL refuses several ranks on one device)."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        self.world = len(self.engines)
+        for r, e in enumerate(self.engines):
+            if e.cfg.ep_world_size != self.world or e.cfg.ep_rank != r:
+                raise RuntimeError("engine %d was built for rank %d of %d" % (r, e.cfg.ep_rank, e.cfg.ep_world_size))
+
+    def forward(self, feats, feat_lens):
+        engs, W = self.engines, self.world
+        rows = [int(f.shape[0]) * e.output_shape(int(f.shape[0]), int(f.shape[1]))[1] for e, f in zip(engs, feats)]
+        cap = max(rows)                                           # agree_capacity: the largest row count of any rank
+        logits, wires, segs = [], [], None
+        for e, f, l in zip(engs, feats, feat_lens):
+            e.set_ep_capacity(cap)
+            logits.append(e.bind(f, l))
+            D = e.cfg.attention_dim
+            wires.append((e.buffer("ep.wire_a").view(W, -1, D), e.buffer("ep.wire_b").view(W, -1, D)))
+            names = e.stage_names()
+            cuts = []
+            for i in range(e.cfg.num_blocks):
+                cuts.append(names.index("blocks.%d.moe_ep.send" % i) + 1)
+                cuts.append(names.index("blocks.%d.moe_ep.expert" % i) + 1)
+            s = list(zip([0] + cuts, cuts + [len(names)]))
+            assert segs is None or len(s) == len(segs)
+            segs = s if segs is None else segs
+            e._segs = s
+        for k in range(len(segs)):
+            for e in engs:
+                a, b = e._segs[k]
+                e.run_stages(a, b)
+            for e in engs:
+                e.stream.synchronize()
+            if k + 1 < len(segs):
+                for i in range(W):                                # rank i's chunk j -> rank j's chunk i
+                    for j in range(W):
+                        wires[j][1][i].copy_(wires[i][0][j])
+                torch.cuda.synchronize()
         return logits

@@ -39,10 +39,15 @@ def _profiler_attached():
     return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
 
 
-if not _profiler_attached():
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-else:
-    print("bench: profiler attached, GPU_MAX_HW_QUEUES left at %s" % os.environ.get("GPU_MAX_HW_QUEUES", "<default>"), file=sys.stderr)
+def _counters_collected():
+    """rocprofv3 --pmc / -i counter file (it exports ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS to the profiled process).
+    Only counter collection needs the bounded-dispatch mode (--pmc-safe); --kernel-trace / --stats runs keep the real
+    configuration (4 contexts, graph replay), so their kernel statistics describe the headline run."""
+    v = os.environ.get("ROCPROF_COUNTER_COLLECTION", "")
+    return bool(os.environ.get("ROCPROF_COUNTERS")) or v not in ("", "0", "False", "false")
+
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -95,11 +100,20 @@ def parse():
                     help="N > 1 replica runs end with a short expert-parallel forward over the same process group, reported "
                          "on stderr and in gpurun_out/ep_probe_nN.json AFTER the JSON line; this switches it off")
     ap.add_argument("--pmc-safe", action="store_true",
-                    help="for `rocprofv3 --pmc ... -- python3 bench.py --pmc-safe`: one execution context and 4 host threads "
-                         "(the counter-collection abort of round 1 followed the host thread count, DESIGN.md 6)")
+                    help="for `rocprofv3 --pmc ... -- python3 bench.py --pmc-safe` (set automatically when counter collection is "
+                         "detected): one execution context, plain launches, a device synchronise per forward -- the profiler's "
+                         "counter-collection thread aborts when thousands of un-synchronised dispatches are in flight (DESIGN.md 6)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed loop of --steps forwards is run this many times (each bracketed by barrier + synchronize); "
+                         "value / ms_per_step are the MEDIAN repeat, every repeat is listed in config.ms_per_step_repeats")
+    ap.add_argument("--ep-probe-strict", action="store_true",
+                    help="N > 1 replica runs: exit non-zero when the expert-parallel probe after the headline line fails or times "
+                         "out (default: the outcome is recorded in gpurun_out/ep_probe_nN.json and on stderr, exit code 0)")
     ap.add_argument("--latency-iters", type=int, default=100, help="hipEvent-timed single forwards for p50 / p99 (>= 50)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
+    ap.add_argument("--ep-probe-inject-failure", action="store_true",
+                    help="diagnostic (tests): make the expert-parallel probe raise, to show that a failing probe is visible")
     return ap.parse_args()
 
 
@@ -189,9 +203,27 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
                 t = weights_full[k].contiguous() if on_host else weights_full[k].to(dev).contiguous()
                 dist.broadcast(t, src=0)
                 weights_full[k] = t.cpu()
-    cfg = EncoderConfig(num_blocks=L, num_experts=E // world, ep_world_size=world, ep_rank=rank, weight_dtype=wdt)
-    eng = Engine.from_state_dict(cfg, weights_full, device=dev)
-    ep = ExpertParallelEncoder(eng)
+    fp8a = bool(getattr(args, "fp8_activations", False)) and wdt == "fp8"
+    h_scales = None
+    if fp8a:
+        # static H scale per MoE layer (m3asr/calibrate.py), from rank 0's batch with all experts local, then broadcast:
+        # every rank must quantise H with the same scale as the single-GPU engine would
+        from m3asr.calibrate import calibrate_h_scales
+        hs = torch.zeros(L, dtype=torch.float32)
+        if rank == 0:
+            hs = torch.tensor(calibrate_h_scales(full, weights_full, [(feat, feat_len)], device=dev), dtype=torch.float32)
+            torch.cuda.empty_cache()
+        if world > 1:
+            t = hs if on_host else hs.to(dev)
+            dist.broadcast(t, src=0)
+            hs = t.cpu()
+        for i in range(L):
+            weights_full["blocks.%d.feed_forward.experts.h_scale" % i] = hs[i:i + 1].clone()
+        h_scales = [round(float(hs.min()), 6), round(float(hs.max()), 6)]
+    cfg = EncoderConfig(num_blocks=L, num_experts=E // world, ep_world_size=world, ep_rank=rank, weight_dtype=wdt,
+                        fp8_activations=fp8a)
+    eng = Engine.from_state_dict(cfg, weights_full, device=dev, ep_stages=True)
+    ep = ExpertParallelEncoder(eng, graph=not args.no_graph)
     ep.bind(feat, feat_len)
 
     def sync():
@@ -200,6 +232,8 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
             dist.barrier()
         torch.cuda.synchronize()
 
+    ep.enqueue()          # the first forward of a binding runs eagerly and (by default) captures the whole forward as one graph
+    sync()
     for _ in range(warmup):
         ep.enqueue()
     sync()
@@ -215,7 +249,8 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
         dist.all_reduce(frames_all, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    _, S, D, bufs = ep._bound
+    _, S, D, cap = ep._bound
+    kern = {st["name"]: st["kernel"] for st in eng.stage_info()}
     touched = []
     for li in range(L):
         g = eng.buffer("blocks.%d.gate_idx" % li, torch.int32).cpu().numpy()
@@ -223,23 +258,28 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
     return {"value": float(frames_all.item()) / (dt / steps), "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
             "frames_per_step_all_ranks": int(frames_all.item()), "batch_per_gpu": B, "padded_frames": T,
             "experts_per_gpu": E // world, "weight_dtype": wdt, "rows_per_rank": S, "packed_rows": bool(B > 1 and eng.packed_rows()),
-            "wire": {"capacity_rows": bufs.cap, "bytes_per_exchange_per_rank": int(bufs.wire_a.numel() * 4),
-                     "collectives_per_forward": 2 * L, "host_syncs_per_forward": 0,
-                     "backend": (dist.get_backend() if world > 1 else "none (one rank: local copy)")},
+            "wire": {"capacity_rows": cap, "bytes_per_exchange_per_rank": int(world * (cap + 1) * D * 4), "wire_dtype": "f32",
+                     "collectives_per_forward": 2 * L, "host_syncs_per_forward": ep.host_syncs_per_forward(),
+                     "backend": (dist.get_backend() if world > 1 else "none (one rank: device copy)")},
+            "forward_graph": ep.graph_state, "expert_kernel": kern.get("blocks.0.moe_ep.expert"),
+            "fp8_activations": fp8a, "h_scale_min_max": h_scales,
             "global_experts_touched_by_rank0_tokens_mean": round(float(np.mean(touched)), 2),
             "kernels_per_forward_native_stages": eng.num_kernels()}
 
 
 def main():
     args = parse()
-    if args.pmc_safe or _profiler_attached():
-        # rocprofv3 --pmc aborts (SIGSEGV in the tool's counter-collection thread) when a hipGraph is captured /
-        # instantiated in the profiled process -- the process survives plan packing, calibration and eager forwards and dies
-        # at the first m3_engine_forward(use_graph=1): profile eager launches on one context
+    downgraded = False
+    if args.pmc_safe or _counters_collected():
+        # rocprofv3 --pmc serialises and instruments every dispatch; its counter-collection thread aborts (SIGSEGV) once
+        # thousands of un-synchronised dispatches are in flight (50 back-to-back forwards x 295 kernels; <= 1 770 survive --
+        # DESIGN.md 6, the one root cause on record).  Counter passes therefore run one context, plain launches and a device
+        # synchronise per forward; --kernel-trace / --stats runs are NOT downgraded.
         args.streams = 1
         args.no_graph = True
         args.latency_iters = 50
         args.pmc_safe = True
+        downgraded = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,7 +324,7 @@ def main():
             if full18 and args.weight_dtype == "bf16" and args.experts == 32 and world == 8 and args.batch == 2 and args.varlen == "50-500":
                 which = "BASELINE.json configs[3]"
             elif full18 and args.weight_dtype == "fp8" and args.experts == 64 and world == 8 and args.batch == 8 and args.varlen == "50-500":
-                which = "BASELINE.json configs[4] (fp8 = e4m3 weight-only experts, bf16 MFMA)"
+                which = "BASELINE.json configs[4] (%s)" % EncoderConfig(weight_dtype="fp8", fp8_activations=bool(args.fp8_activations)).fp8_label()
             else:
                 which = "not a BASELINE.json config (same path at another size)"
             out = {"metric": "encoder frames/sec, %dLx%de Conformer-MoE, expert parallel, batch=%d per GPU %s" % (
@@ -294,7 +334,7 @@ def main():
                    "dtype": args.weight_dtype, "data": "synthetic",
                    "config": {"workload": "%d-layer %d-expert %s, expert-parallel %d experts/GPU x %d GPU, batch %d per GPU (%s)" % (
                                   args.layers, args.experts, args.weight_dtype, r["experts_per_gpu"], world, args.batch, which),
-                              "parallelism": "ep%d x dp%d" % (world, world), "hip_graph": False, **{k: v for k, v in r.items() if k not in ("value", "ms_per_step", "steps", "warmup")}},
+                              "parallelism": "ep%d x dp%d" % (world, world), "hip_graph": r["forward_graph"] in ("captured", "engine graph"), **{k: v for k, v in r.items() if k not in ("value", "ms_per_step", "steps", "warmup")}},
                    "roofline": None, "cpu_baseline": None}
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -365,17 +405,26 @@ def main():
     phase("warm-up enqueued")
     barrier()
     phase("warm-up done (device synchronised)")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ctxs[i % len(ctxs)].forward(use_graph=use_graph)
-    for c in ctxs:
-        c.stream.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # the timed region: EXACTLY --steps forwards between barrier + synchronize on both sides, max over ranks; repeated
+    # --repeats times so that a short run (the driver's 20 steps = 20 ms) is not a single 20 ms sample: value = median repeat
+    rep_dt = []
+    for _ in range(max(1, 1 if args.pmc_safe else args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ctxs[i % len(ctxs)].forward(use_graph=use_graph)
+            if args.pmc_safe:
+                ctxs[i % len(ctxs)].stream.synchronize()
+        for c in ctxs:
+            c.stream.synchronize()
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        rep_dt.append(d)
+    dt = float(np.median(rep_dt))
     ms_per_step = dt / args.steps * 1e3
     phase("timed region done")
     # latency of one forward when it has the GPU to itself (one context): back-to-back mean, and the distribution of
@@ -421,7 +470,13 @@ def main():
         extra = (F + D) * 4 * (2 if cfg.weight_dtype == "fp8" else 1)
         exp_bytes = [t_ * (2 * D * F * wsz + extra) + live * 2 * D * 4 for t_ in touched]
         peak_bw = 8000.0                                                        # GB/s (MI355X_MICROARCH.md)
-        peak_tf = {"f32": 157.3, "bf16": 2500.0, "fp8": 2500.0}[cfg.weight_dtype]   # dense MFMA TFLOP/s of the arithmetic
+        # dense MFMA TFLOP/s (MI355X_MICROARCH.md): fp32 / bf16 by the instruction's own rate; fp8 against the CHIP's fp8 peak
+        # (5 PF, reached only by v_mfma_scale_f32_32x32x64_f8f6f4) when the engine computes in fp8, against the bf16 peak
+        # when fp8 is weight storage only (W8A16: the MFMAs are bf16)
+        peak_tf = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0 if cfg.fp8_activations else 2500.0}[cfg.weight_dtype]
+        peak_note = {"f32": "v_mfma_f32_16x16x4_f32 (fp32 in, exact)", "bf16": "bf16 MFMA dense",
+                     "fp8": ("chip fp8 dense peak (fp8 arithmetic in the grouped expert FFN)" if cfg.fp8_activations
+                             else "bf16 MFMA dense (fp8 is weight storage only: W8A16)")}[cfg.weight_dtype]
         fam, li = {}, 0
         tot_bytes = tot_flops = 0.0
         for st, t_ms in zip(info, ms):
@@ -493,7 +548,7 @@ def main():
         # correction of MI355X_MICROARCH.md (HBM).  null when no summary of this exact workload is committed.
         for r_ in (roofline, roofline_expert):
             r_["traffic"] = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
         if os.path.exists(pmc):
             try:
                 ent = json.load(open(pmc))
@@ -503,7 +558,7 @@ def main():
                         if k_:
                             n_l_ = float(sum(v["launches"] for v in k_))      # launch-weighted over the family's template variants
                             r_["traffic"] = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in k_) / max(n_l_, 1.0))
-                            r_["traffic_source"] = "profiles/r02_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe)"
+                            r_["traffic_source"] = "profiles/r03_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe, timed-workload launches only)"
             except Exception:
                 pass
         forward = {"alg_bytes": int(tot_bytes), "flops": int(tot_flops),
@@ -512,7 +567,7 @@ def main():
                    "hbm_frac_one_stream": round(tot_bytes / (float(np.median(lat)) * 1e-3) / (peak_bw * 1e9), 4),
                    "hbm_frac_at_value": round(tot_bytes * (value / frames_per_step) / (peak_bw * 1e9), 4),
                    "mfma_frac_at_value": round(tot_flops * (value / frames_per_step) / (peak_tf * 1e12), 4),
-                   "mfma_peak_tflops": peak_tf, "live_rows": live, "padded_rows": S}
+                   "mfma_peak_tflops": peak_tf, "mfma_peak_is": peak_note, "live_rows": live, "padded_rows": S}
 
     # ---- CPU baseline: the oracle (plain-torch fp32 restatement) on the host cores, rank 0, N=1 only ----
     cpu = None
@@ -592,31 +647,60 @@ def main():
                           "frames_per_s_one_stream": round(n_frames / (latency_ms * 1e-3), 1), "hip_graph": use_graph,
                           "h_scale_min_max": fp8_h_scales, "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
                           "routing": args.routing, "route_mode": ["staged", "fused", "split"][route],
-                          "packed_rows": bool(B > 1 and eng.packed_rows())},
+                          "packed_rows": bool(B > 1 and eng.packed_rows()),
+                          "timed_region": "median of %d repeats of %d forwards" % (len(rep_dt), args.steps),
+                          "ms_per_step_repeats": [round(d_ / args.steps * 1e3, 4) for d_ in rep_dt],
+                          "profiler_downgraded": downgraded,
+                          "h_scale_calibrated_on": ("the benchmark batch itself (untimed set-up)" if args.fp8_activations else None)},
                "roofline": roofline, "roofline_expert": roofline_expert, "forward": forward, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1 and not args.no_ep_probe and weights is not None:
         # After the headline line: a short expert-parallel run over the same process group (configs[3]-shaped: bf16, 2
         # ragged utterances per GPU, experts sharded E / N), so that a multi-GPU run also exercises the all-to-all path.
-        # Reported on stderr and in gpurun_out/; guarded: whatever happens here, the process ends with exit code 0.
+        # The outcome -- status ok / failed / timeout, the measurement or the exception -- goes to stderr and to
+        # gpurun_out/ep_probe_nN.json.  The headline line is already out; the exit code stays 0 unless --ep-probe-strict.
         import threading
-        threading.Timer(150.0, lambda: os._exit(0)).start()
+        probe_path = os.path.join(ROOT, "gpurun_out", "ep_probe_n%d.json" % world)
+
+        def record(status, payload):
+            payload = dict(payload, status=status, n_gpus=world, rank=rank)
+            print("ep_probe status=%s rank=%d %s" % (status, rank, json.dumps(payload)), file=sys.stderr, flush=True)
+            if rank == 0 or status != "ok":
+                try:
+                    os.makedirs(os.path.dirname(probe_path), exist_ok=True)
+                    with open(probe_path if rank == 0 else probe_path.replace(".json", "_rank%d.json" % rank), "w") as f:
+                        json.dump(payload, f)
+                except OSError:
+                    pass
+
+        def on_timeout():                # a hung collective cannot be unwound: say so, then leave
+            record("timeout", {"what": "expert-parallel probe did not finish within 150 s (hung collective or device)"})
+            sys.stdout.flush()
+            os._exit(3 if args.ep_probe_strict else 0)
+
+        timer = threading.Timer(150.0, on_timeout)
+        timer.daemon = True
+        timer.start()
+        rc = 0
         try:
-            if args.experts % world == 0:
+            if args.ep_probe_inject_failure:
+                raise RuntimeError("injected failure (--ep-probe-inject-failure)")
+            if args.experts % world:
+                record("skipped", {"what": "%d experts do not divide over %d ranks" % (args.experts, world)})
+            else:
                 r = run_ep(args, rank, world, dev, dist, weights, 10, 2, "bf16", 2, "50-500", 0, balanced=True)
                 if rank == 0:
                     r["what"] = "expert-parallel probe after the replica benchmark: %dL/%de bf16, %d experts/GPU, 2 utterances U[50,500] per GPU" % (
                         args.layers, args.experts, args.experts // world)
-                    r["n_gpus"] = world
-                    print("ep_probe " + json.dumps(r), file=sys.stderr, flush=True)
-                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-                    with open(os.path.join(ROOT, "gpurun_out", "ep_probe_n%d.json" % world), "w") as f:
-                        json.dump(r, f)
-        except BaseException as ex:      # noqa: BLE001 -- the probe must never take the benchmark's exit code with it
-            print("ep_probe failed on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
+                    record("ok", r)
+        except BaseException as ex:      # noqa: BLE001 -- recorded, not swallowed: status "failed" with the exception
+            record("failed", {"what": "expert-parallel probe raised", "exception": repr(ex)})
+            rc = 4 if args.ep_probe_strict else 0
+        timer.cancel()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        if rc:
+            os._exit(rc)                 # a failed collective may have left the group unusable: do not wait on it
     if world > 1:
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 6
+#define M3ASR_ABI_VERSION 7
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -345,6 +345,9 @@ typedef struct m3_engine_config {
                                   * fp8 kernel applies (long batches): rows quantised per row, H with the static per-layer
                                   * scale "blocks.N.feed_forward.experts.h_scale" of the plan (calibrated); elsewhere the
                                   * weight-only form runs */
+  int32_t ep_stages;             /* 1 = build the expert-parallel stage list ("blocks.N.moe_ep.send / .expert / .combine")
+                                  * even with ep_world_size <= 1: a one-rank rehearsal of the exchange, the two all-to-alls
+                                  * being device copies ("moe_ep.exchange1 / 2" stages).  ep_world_size > 1 always builds it */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {
@@ -371,6 +374,12 @@ int m3_engine_forward(m3_engine* engine, const float* feat, const int32_t* feat_
  * local index -> RCCL all-to-all -> m3_moe_expert_ffn on the received rows -> all-to-all back -> combine. */
 int m3_engine_prepare(m3_engine* engine, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
                       void* workspace, size_t workspace_bytes);
+/* Expert parallel: rows per wire chunk for the bindings made from now on (what the ranks agreed on: the largest row
+ * count B*T' of any rank, so that a rank may send all of its rows to one peer; 0 = this rank's own row count).  The wire
+ * buffers "ep.wire_a" / "ep.wire_b" ([world][1 + rows_per_chunk][D] fp32 each, inside the workspace) are what the host
+ * hands to the all-to-all: after "blocks.N.moe_ep.send" exchange wire_a -> wire_b, after "blocks.N.moe_ep.expert" again
+ * wire_a -> wire_b, then "blocks.N.moe_ep.combine".  Semantics: trainer_3m_fix/fmoe/functions.py:13-86,175-199. */
+int m3_engine_set_ep_capacity(m3_engine* engine, int rows_per_chunk);
 int m3_engine_num_stages(const m3_engine* engine);
 int m3_engine_num_captures(const m3_engine* engine); /* hipGraphs captured so far (a cache hit replays, it does not capture) */
 const char* m3_engine_stage_name(const m3_engine* engine, int index);

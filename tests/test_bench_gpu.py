@@ -37,6 +37,9 @@ def test_bench_default_contract_small_model():
     lat = d["forward"]["latency_ms"]
     assert lat["n"] >= 50 and lat["min"] <= lat["p50"] <= lat["p99"]
     assert "not a BASELINE.json config" in d["config"]["workload"]         # 2 layers: must not be labelled configs[1]
+    # the timed region is repeated; value is the median repeat of exactly `steps` forwards
+    reps = d["config"]["ms_per_step_repeats"]
+    assert len(reps) >= 5 and min(reps) <= d["ms_per_step"] <= max(reps) and d["config"]["profiler_downgraded"] is False
 
 
 def test_bench_fp8_arithmetic_small_model():
@@ -47,3 +50,5 @@ def test_bench_fp8_arithmetic_small_model():
     assert 0 < lo <= hi < 1.0
     assert d["roofline_expert"]["kernel"] == "expert_ffn_fused_fp8_kernel", d["roofline_expert"]["kernel"]
     assert d["config"]["packed_rows"] is True
+    assert d["forward"]["mfma_peak_tflops"] == 5000.0 and "fp8" in d["forward"]["mfma_peak_is"]     # priced against the chip's fp8 peak
+    assert "benchmark batch" in d["config"]["h_scale_calibrated_on"]

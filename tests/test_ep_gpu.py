@@ -1,5 +1,6 @@
 """GPU: the expert-parallel driver on the HIP backend.
- * world 1: ExpertParallelEncoder (staged engine + ep_moe_layer through the C ABI) == fused engine, bit for bit.
+ * world 1: ExpertParallelEncoder over an engine with the expert-parallel stage list (ep_stages: index on global ids, wire,
+   exchange as a device copy, receive-side grouped FFN, combine) == the all-experts-local engine, bit for bit.
  * world 2 on ONE GPU: two processes share cuda:0, experts sharded 2+2, gloo transport staged through the host
    (RCCL refuses two ranks on one device); each rank's logits must match the CPU oracle with all experts local."""
 import os
@@ -27,7 +28,7 @@ def test_ep_world1_equals_fused_engine():
     fl = torch.tensor([[120, 77]], dtype=torch.int32).cuda()
     # the EP driver replaces the moe_local.* stages of the staged (unfused-route) engine: same kernels, same order
     staged = Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False)(feat, fl).clone()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False))
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, ep_stages=True, packed_rows=False))
     assert torch.equal(ep.forward(feat, fl), staged)
     # fuse_route engines do router + top-1 + index in one launch (different summation order in the router)
     fused = Engine.from_state_dict(cfg, w, fuse_route=True)(feat, fl)
@@ -44,11 +45,13 @@ def test_ep_world1_on_packed_rows_equals_engine():
     eng = Engine.from_state_dict(cfg, w, fuse_route=False)
     want = eng(feat, fl).clone()
     assert eng.packed_rows()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, fuse_route=False))
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, ep_stages=True))
     got = ep.forward(feat, fl)
     assert ep.eng.packed_rows()
     assert torch.equal(got, want)
-    # a second forward on the same binding re-uses the buffers (nothing is allocated or synchronised per layer)
+    # later forwards of the binding replay one graph (stages + exchanges): nothing is allocated or synchronised per layer
+    assert torch.equal(ep.forward(feat, fl), want)
+    assert ep.graph_state == "engine graph"
     assert torch.equal(ep.forward(feat, fl), want)
 
 
@@ -73,12 +76,23 @@ def test_bench_expert_parallel_rehearsal_two_ranks_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["experts_per_gpu"] == 16
-    assert line["config"]["wire"]["host_syncs_per_forward"] == 0 and line["config"]["wire"]["collectives_per_forward"] == 4
+    # (the gloo rehearsal stages every exchange through the host: 2 synchronisations per layer; RCCL: none)
+    assert line["config"]["wire"]["host_syncs_per_forward"] == 4 and line["config"]["wire"]["collectives_per_forward"] == 4
+    assert line["config"]["forward_graph"].startswith("eager: the gloo transport")
     r = subprocess.run(base + ["--streams", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "replicas x2"
-    assert "ep_probe {" in r.stderr, r.stderr[-2000:]
+    assert "ep_probe status=ok" in r.stderr, r.stderr[-2000:]
+    probe = json.load(open(os.path.join(root, "gpurun_out", "ep_probe_n2.json")))
+    assert probe["status"] == "ok" and probe["value"] > 0
+    # a failing probe is visible: status "failed" + the exception on stderr and in the file, exit code non-zero when strict
+    r = subprocess.run(base + ["--streams", "2", "--ep-probe-inject-failure", "--ep-probe-strict"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode != 0
+    assert [l for l in r.stdout.splitlines() if l.startswith("{")], "the headline line must still be printed"
+    assert "ep_probe status=failed" in r.stderr and "injected failure" in r.stderr
+    assert json.load(open(os.path.join(root, "gpurun_out", "ep_probe_n2.json")))["status"] == "failed"
 
 
 def test_ep_world1_bf16_equals_engine():
@@ -92,14 +106,14 @@ def test_ep_world1_bf16_equals_engine():
         fl = torch.tensor([[T - 13 * i for i in range(B)]], dtype=torch.int32).cuda()
         eng = Engine.from_state_dict(cfg, w, bf16_activations=False, packed_rows=False)
         want = eng(feat, fl).clone()
-        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, bf16_activations=False, packed_rows=False))
+        ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, bf16_activations=False, packed_rows=False, ep_stages=True))
         assert torch.equal(ep.forward(feat, fl), want)
         if B == 16:      # the default engine keeps bf16 activation operands at this size (a bf16 copy of x that every kernel
             # writing x maintains): the driver's combine (m3_moe_combine_bf16) maintains it too -- bit for bit again
             eng16 = Engine.from_state_dict(cfg, w, packed_rows=False)
             want16 = eng16(feat, fl).clone()
             assert eng16.buffer("xb", torch.bfloat16) is not None
-            ep16 = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False))
+            ep16 = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False, ep_stages=True))
             assert torch.equal(ep16.forward(feat, fl), want16)
             assert not torch.equal(want16, want)        # (the two modes do differ: bf16 activation operands are in use)
 
@@ -147,3 +161,62 @@ def test_ep_ranks_on_one_gpu(tmp_path, world, wdt):
             assert err <= 2e-4 + 1e-3 * scale, (r, err)
         else:      # same expert arithmetic; the multi-rank engine takes top-1 and index in two kernels, the single-rank one in a
             assert err <= 1e-5 * scale + 1e-6, (r, err)   # fused kernel (gate value summed in another order: last-ulp noise)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8_arithmetic"])
+def test_ep_world8_real_dims_one_process(mode):
+    """BASELINE.json configs[3] / configs[4] at REAL dimensions and world 8, on one GPU: 8 rank engines in one process
+    (m3asr.ep.InProcessRanks: every native stage and wire format is the real one, the all-to-all is a device copy between
+    the ranks' wire buffers -- a GPU box admits neither 8 processes on its card nor RCCL ranks sharing a device).
+      bf16:           32 experts, 4 per rank, 2 ragged utterances U[50,500] per rank   (configs[3], 4 of its 18 layers)
+      fp8 arithmetic: 64 experts, 8 per rank, 8 ragged utterances per rank, calibrated H scales (configs[4], 4 layers);
+                      the receive side must run the fused fp8 kernel (e4m3 x e4m3 MFMA), not the weight-only form
+    Reference = ONE engine of the same precision with all experts local on the union batch (16 / 64 utterances): same
+    kernels on the same rows up to the order of rows inside an expert, which the grouped GEMMs do not depend on."""
+    from m3asr.ep import InProcessRanks
+    world = 8
+    fp8 = mode == "fp8_arithmetic"
+    E, per_rank = (64, 8) if fp8 else (32, 2)
+    wdt = "fp8" if fp8 else "bf16"
+    full = EncoderConfig(num_blocks=4, num_experts=E, weight_dtype=wdt, fp8_activations=fp8)
+    w = make_weights(full, seed=21)
+    rng = np.random.default_rng(77)
+    B = world * per_rank
+    lengths = rng.integers(50, 501, B)
+    lengths[::per_rank] = 500                                    # every rank's padded length is 500 (one shape for all)
+    feat = torch.from_numpy(rng.random((B, 500, full.input_dim), dtype=np.float32))
+    fl = torch.from_numpy(lengths.astype(np.int32))
+    if fp8:
+        from m3asr.calibrate import calibrate_h_scales
+        calibrate_h_scales(full, w, [(feat[:16], fl[:16])])
+    ref_eng = Engine.from_state_dict(full, w)
+    want = ref_eng(feat.cuda(), fl.view(1, -1).cuda()).cpu()
+    kern = {s_["name"]: s_["kernel"] for s_ in ref_eng.stage_info()}
+    ref_gate = torch.stack([ref_eng.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(B, -1)
+                            for i in range(full.num_blocks)])
+    if fp8:
+        assert kern["blocks.0.moe_local.expert"] == "expert_ffn_fused_fp8_kernel"
+    del ref_eng
+    torch.cuda.empty_cache()
+    engines = []
+    for r in range(world):
+        cfg = EncoderConfig(num_blocks=4, num_experts=E // world, ep_world_size=world, ep_rank=r, weight_dtype=wdt, fp8_activations=fp8)
+        engines.append(Engine.from_state_dict(cfg, w))
+    feats = [feat[r * per_rank:(r + 1) * per_rank].cuda().contiguous() for r in range(world)]
+    lens = [fl[r * per_rank:(r + 1) * per_rank].view(1, -1).cuda().contiguous() for r in range(world)]
+    outs = InProcessRanks(engines).forward(feats, lens)
+    ek = {s_["name"]: s_["kernel"] for s_ in engines[0].stage_info()}["blocks.0.moe_ep.expert"]
+    if fp8:
+        assert ek == "expert_ffn_fused_fp8_kernel", ek
+    got = torch.cat([o.cpu() for o in outs])
+    Tp = got.shape[1]
+    valid = torch.arange(Tp).view(1, -1) < sub_len(fl.long()).view(-1, 1)
+    gate = torch.cat([torch.stack([e.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(per_rank, -1)
+                                   for i in range(full.num_blocks)]) for e in engines], dim=1)
+    agree = float((gate[:, valid] == ref_gate[:, valid]).float().mean())
+    err = float((got - want).abs()[valid].max()) / float(want.abs()[valid].max())
+    print("EP world 8 (%s, %d experts, %d per rank, %d utterances per rank, receive-side kernel %s): max |err| / max |logit| "
+          "= %.3e vs the all-experts-local engine, routing agreement %.5f" % (mode, E, E // world, per_rank, ek, err, agree))
+    assert bool((got[~valid] == 0).all())
+    assert agree >= 0.999, agree
+    assert err <= (2e-3 if fp8 else 1e-4), err

@@ -218,7 +218,7 @@ def test_ep_world1_fp8_equals_engine():
     feat = torch.rand(2, 120, cfg.input_dim, generator=torch.Generator().manual_seed(2)).cuda()
     fl = torch.tensor([[120, 107]], dtype=torch.int32).cuda()
     want = Engine.from_state_dict(cfg, w, packed_rows=False)(feat, fl).clone()
-    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False))
+    ep = ExpertParallelEncoder(Engine.from_state_dict(cfg, w, packed_rows=False, ep_stages=True))
     assert torch.equal(ep.forward(feat, fl), want)
 
 
