@@ -26,14 +26,33 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
                                                               const float* __restrict__ pos_v,
                                                               const int32_t* __restrict__ row_len, int T, int D,
                                                               float scale, float* __restrict__ out, int ldo, int out_bf16,
-                                                              const int32_t* __restrict__ row0) {
+                                                              const int32_t* __restrict__ row0, int QT, int H, int xcd_map) {
   constexpr int KS = DK / 16;
   __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
   __shared__ float mo[4][16][DK + 1];   // per-wave partial O
   __shared__ float mm[4][16], ml[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
   float (*ps)[20] = ps_all[wave];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
+  // work-group -> (batch, head, query tile).  The QT query tiles of one (batch, head) read the same K / V / P rows: with
+  // xcd_map they get block ids that are congruent mod 8, i.e. one XCD and one L2 (blocks are dealt round-robin over the 8
+  // XCDs), so those rows leave memory once instead of once per query tile (PMC: 1.55 MB -> see DESIGN.md 3).  Placement
+  // only changes speed, never the result.
+  int b, h, q0;
+  {
+    const int id = blockIdx.x;
+    int bh, qt;
+    if (xcd_map) {
+      const int g = id & 7, slot = id >> 3;
+      bh = (slot / QT) * 8 + g;
+      qt = slot - (slot / QT) * QT;
+    } else {
+      bh = id / QT;
+      qt = id - bh * QT;
+    }
+    b = bh / H;
+    h = bh - b * H;
+    q0 = qt * 16;
+  }
   const int len = min(row_len ? row_len[b] : T, T);
   // packed rows (row0 != null): utterance b owns rows [row0[b], row0[b] + len) -- nothing beyond its last frame may be
   // read (it is another utterance's) or written; padded rows: [b T, (b+1) T), frames >= len hold defined values
@@ -147,11 +166,13 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
                             float* out, int ldo, hipStream_t stream, int out_bf16, const int32_t* row0) {
   M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
   M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0, "attention: row strides must be multiples of 4");
-  dim3 grid(cdiv(T, 16), H, B);
+  const int QT = cdiv(T, 16);
+  dim3 grid(QT * H * B);
   const int D = H * dk;
+  const int xcd_map = ((H * B) % 8 == 0) ? 1 : 0;
 #define M3_ATT_CASE(DK_)                                                                                   \
   hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
-                     pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0)
+                     pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0, QT, H, xcd_map)
   switch (dk) {
     case 16: M3_ATT_CASE(16); break;
     case 32: M3_ATT_CASE(32); break;

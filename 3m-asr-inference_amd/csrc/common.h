@@ -79,6 +79,19 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Weights that a launch reads exactly once (the skinny GEMMs and the B=1 expert kernel stream 1-107 MB of them per launch):
+// non-temporal loads keep them from displacing the activation rows, which every work-group re-reads, in L1 / L2
+// (MI355X_MICROARCH.md: `nt` loads are L2-served, bypass L1).  -DM3_NT_WEIGHTS=0 builds the plain-load variant for A/B runs.
+#ifndef M3_NT_WEIGHTS
+#define M3_NT_WEIGHTS 1
+#endif
+__device__ __forceinline__ f32x4 ldg4_w(const float* p) {
+#if M3_NT_WEIGHTS
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
 
 // D = A(16x4) * B(4x16) + C, exact f32 (v_mfma_f32_16x16x4_f32).
 // lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c[r] = C[(l>>4)*4 + r][l&15].
@@ -91,6 +104,13 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 ldg8h(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 ldg8h_w(const bf16_t* p) {   // once-read weights, see ldg4_w
+#if M3_NT_WEIGHTS
+  return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#else
+  return *reinterpret_cast<const bf16x8*>(p);
+#endif
+}
 // 8 consecutive floats -> 8 bf16 (round to nearest even: v_cvt_pk_bf16_f32)
 __device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
   bf16x8 r;
@@ -111,6 +131,13 @@ __device__ __forceinline__ f32x4 mfma16h(bf16x8 a, bf16x8 b, f32x4 c) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 ldg16b(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 ldg16b_w(const void* p) {     // once-read weights, see ldg4_w
+#if M3_NT_WEIGHTS
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+  return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
 // 8 consecutive fp8 (two dwords) -> bf16x8, element order preserved
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
   const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);

@@ -92,6 +92,9 @@ struct m3_engine {
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
     int ep_cap = 0;        // expert parallel: rows per wire chunk this binding was built for (m3_engine_set_ep_capacity)
+    // fork_embed: stages [fork_first, fork_mid) = the embed encoder (side branch of the captured graph), [fork_mid, join_at) =
+    // what the main encoder does before it needs the embedding; -1 = one linear chain
+    int fork_first = -1, fork_mid = -1, join_at = -1;
     // fold_pos_proj: linear_pos(pe[:T']) of every block, computed once per T'.  ENGINE-owned device memory (shared by all
     // bindings of the same T', freed with the last of them): a caller that reuses one workspace for several shapes, as a
     // TensorRT execution context does, must not be able to overwrite it between two forwards of a revived binding
@@ -112,6 +115,8 @@ struct m3_engine {
   uint64_t use_clock = 0;
   int n_captures = 0;                                      // graphs captured so far (observability / tests)
   int ep_capacity = 0;                                     // rows per wire chunk agreed by the ranks for the NEXT bindings (0 = own rows)
+  hipStream_t side = nullptr;                              // second capture stream: the embed branch of forked graphs
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::unordered_map<int, std::weak_ptr<float>> pfold_by_tp;   // T' -> folded positional projection still in use
 };
 
@@ -257,8 +262,18 @@ struct Plan {
   // expert parallel (ep_world_size > 1): send-side index over GLOBAL expert ids, the two wire buffers [world][1 + C][D]
   // and the receive-side gate; the MoE workspace is then sized for the world * (1 + C) rows a rank can receive
   int32_t *ep_acc, *ep_mapping, *ep_pos, *ep_map_send, *ep_gate_recv; float *wire_a, *wire_b; int ep_cap, ep_rows;
+  // fork_embed: the embed encoder runs on its own graph branch beside the main subsampler and block 0 up to its router
+  // (conformer_fmoe_..._hier.py:206-215: embed is needed first by blocks.0's router), so it owns a second set of scratch
+  bool fork;
+  float *e_c1, *e_c2, *e_x, *e_h1, *e_qkv, *e_ctx, *e_glu, *e_dw, *e_xpad, *e_splitk; void *e_xb, *e_xbpad;
   size_t bytes;
 };
+
+// short inputs only: a long batch fills the chip with every kernel, two concurrent branches would just take turns
+bool use_fork_embed(const m3_engine_config& c, int B, int S) {
+  if (c.fork_embed < 0 || c.debug_taps) return false;
+  return c.fork_embed > 0 || S <= 512;
+}
 
 // the blocks run on packed rows: B > 1 (or forced), no per-block taps (they are read as (B, T', D)), staged route
 bool use_packed_rows(const m3_engine_config& c, int B) {
@@ -331,8 +346,35 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
     p.xbpad = cv.take<uint16_t>((size_t)S * D);
     p.lpk = cv.take<float>((size_t)S * c.output_dim);
   }
+  p.fork = use_fork_embed(c, B, S);
+  p.e_c1 = p.c1; p.e_c2 = p.c2; p.e_x = p.x; p.e_h1 = p.h1; p.e_qkv = p.qkv; p.e_ctx = p.ctx; p.e_glu = p.glu; p.e_dw = p.dw;
+  p.e_xb = p.xb; p.e_xpad = p.xpad; p.e_xbpad = p.xbpad; p.e_splitk = p.splitk;
+  if (p.fork) {
+    p.e_c1 = cv.take<float>((size_t)B * T1 * F1 * D);
+    p.e_c2 = cv.take<float>((size_t)S * F2 * D);
+    p.e_x = cv.take<float>((size_t)S * D);
+    p.e_xb = cv.take<uint16_t>((size_t)S * D);
+    p.e_h1 = cv.take<float>((size_t)S * F);
+    p.e_qkv = cv.take<float>((size_t)S * 3 * D);
+    p.e_ctx = cv.take<float>((size_t)S * D);
+    p.e_glu = cv.take<float>((size_t)S * D);
+    p.e_dw = cv.take<float>((size_t)S * D);
+    if (p.splitk_bytes) p.e_splitk = cv.take<float>(p.splitk_bytes / sizeof(float));
+    if (p.xpad) {
+      p.e_xpad = cv.take<float>((size_t)S * D);
+      p.e_xbpad = cv.take<uint16_t>((size_t)S * D);
+    }
+  }
   p.bytes = cv.off;
   return p;
+}
+
+// the same plan with the embed branch's scratch under the usual names (what the embed encoder's stages are built from)
+Plan embed_view(const Plan& pl) {
+  Plan q = pl;
+  q.c1 = pl.e_c1; q.c2 = pl.e_c2; q.x = pl.e_x; q.h1 = pl.e_h1; q.qkv = pl.e_qkv; q.ctx = pl.e_ctx; q.glu = pl.e_glu; q.dw = pl.e_dw;
+  q.xb = pl.e_xb; q.xpad = pl.e_xpad; q.xbpad = pl.e_xbpad; q.splitk = pl.e_splitk;
+  return q;
 }
 
 }  // namespace
@@ -764,6 +806,9 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
 
 void m3_engine_destroy(m3_engine* engine) {
   if (!engine) return;
+  if (engine->ev_fork) (void)hipEventDestroy(engine->ev_fork);
+  if (engine->ev_join) (void)hipEventDestroy(engine->ev_join);
+  if (engine->side) (void)hipStreamDestroy(engine->side);
   if (engine->cur.graph_exec) (void)hipGraphExecDestroy(engine->cur.graph_exec);
   for (auto& b : engine->parked)
     if (b.graph_exec) (void)hipGraphExecDestroy(b.graph_exec);
@@ -874,12 +919,16 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     }
   }
   // ---- embed encoder (conformer_embed_domain_acc.py:149-181) ----
-  build_subsample(e, "embed.subsample.", e->sub_e, De, pl, pl.x);
+  const Plan ple = embed_view(pl);
+  if (pl.fork) e->cur.fork_first = (int)e->cur.stages.size();
+  e->cur.splitk_ws = ple.splitk;
+  build_subsample(e, "embed.subsample.", e->sub_e, De, ple, ple.x);
   for (int i = 0; i < c.embed_blocks; ++i)
     build_block(e, "embed.blocks." + std::to_string(i) + ".", e->eblocks[i], De, c.embed_linear_units, c.embed_heads,
-                c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, pl);
+                c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, ple);
+  e->cur.splitk_ws = pl.splitk;
   {
-    float* x = pl.x; float* emb = pl.emb;
+    float* x = ple.x; float* emb = pl.emb;
     const float* g = e->e_after.g; const float* b = e->e_after.b;
     add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); },
               stage_info("layernorm_kernel", 1, 8.0 * S * De, 8.0 * S * De));
@@ -894,6 +943,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     add_gemm(e, "router_e_all", g, true);
   }
   // ---- main MoE encoder (conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) ----
+  if (pl.fork) e->cur.fork_mid = (int)e->cur.stages.size();
   build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);
   for (int i = 0; i < c.num_blocks; ++i)
     build_block(e, "blocks." + std::to_string(i) + ".", e->mblocks[i], D, c.hidden_units, c.attention_heads,
@@ -922,6 +972,14 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
       add_stage(e, "unpack", 1, [=](hipStream_t s) { return launch_unpack_rows(lout, row0, B, Tp, V, logits, s); },
                 stage_info("unpack_rows_kernel", 1, 8.0 * S * V, 0.0, false));
     }
+  }
+  if (pl.fork) {     // the main branch joins the embed branch at the first stage that reads the embedding: blocks.0's router
+    for (size_t i = 0; i < e->cur.stages.size(); ++i)
+      if (e->cur.stages[i].name == "blocks.0.moe_router" || e->cur.stages[i].name == "blocks.0.moe_route") {
+        e->cur.join_at = (int)i;
+        break;
+      }
+    if (e->cur.join_at < 0 || c.num_blocks < 1) e->cur.fork_first = e->cur.fork_mid = e->cur.join_at = -1;
   }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
@@ -992,8 +1050,31 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
       e->cur.graph_exec = nullptr;
     }
     hipGraph_t graph = nullptr;
+    const int n_st = (int)e->cur.stages.size();
+    const bool fork = e->cur.fork_first >= 0 && e->cur.fork_mid > e->cur.fork_first && e->cur.join_at > e->cur.fork_mid;
+    if (fork && e->side == nullptr) {
+      M3_CHECK_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+      M3_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+      M3_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
     M3_CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    int rc = m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
+    int rc = 0;
+    if (!fork) {
+      rc = m3_engine_run(e, 0, n_st, stream_);
+    } else {
+      // two branches between "lens" and blocks.0's router: the embed encoder on the side stream (it joins the capture through
+      // the fork event), the main subsampler + block 0 up to its router on the capture stream
+      hipError_t he = hipSuccess;
+      rc = m3_engine_run(e, 0, e->cur.fork_first, stream_);
+      if (!rc && (he = hipEventRecord(e->ev_fork, stream)) != hipSuccess) rc = -1;
+      if (!rc && (he = hipStreamWaitEvent(e->side, e->ev_fork, 0)) != hipSuccess) rc = -1;
+      if (!rc) rc = m3_engine_run(e, e->cur.fork_first, e->cur.fork_mid, (m3_stream)e->side);
+      if (!rc) rc = m3_engine_run(e, e->cur.fork_mid, e->cur.join_at, stream_);
+      if (!rc && (he = hipEventRecord(e->ev_join, e->side)) != hipSuccess) rc = -1;
+      if (!rc && (he = hipStreamWaitEvent(stream, e->ev_join, 0)) != hipSuccess) rc = -1;
+      if (!rc) rc = m3_engine_run(e, e->cur.join_at, n_st, stream_);
+      if (he != hipSuccess) set_error("engine_forward: forked capture failed: %s", hipGetErrorString(he));
+    }
     hipError_t ce = hipStreamEndCapture(stream, &graph);
     if (rc) {
       if (graph) (void)hipGraphDestroy(graph);

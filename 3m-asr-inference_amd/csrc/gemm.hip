@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
       const int s = min(wave + NW * (G * g + i), nsteps - 1);
       const int k = s << 4;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg4(wrow[t] + k);
+      for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg4_w(wrow[t] + k);
       const bool second = !CONV && p.mode == GEMM_A_CONCAT2 && k >= p.K1;
       const int off = second ? (k - p.K1) : a_offset(k);
 #pragma unroll

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16w_kernel(const GemmParams p)
       const int s = min(wave + NW * (G * g + i), nsteps - 1);   // clamped: no branch around the loads
       const int k = s << 5;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg8h(wrow[t] + k);
+      for (int t = 0; t < NT; ++t) wbuf[buf][i][t] = ldg8h_w(wrow[t] + k);
       const int off = a_offset(k);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_splitk_kernel(const GemmParam
 #pragma unroll
     for (int j = 0; j < JA; ++j) areg[j] = ldg4(aptr[j] + ko);
 #pragma unroll
-    for (int j = 0; j < JB; ++j) breg[j] = ldg4(bptr[j] + s * SBK);
+    for (int j = 0; j < JB; ++j) breg[j] = ldg4_w(bptr[j] + s * SBK);
   };
   auto store_tiles = [&](int buf) {
     float* a_dst = As + buf * (SBM * S_LD) + ar0 * S_LD + 4 * ac;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int s = min(8 * g + i, ksteps1 - 1);   // clamped, not branched: loads stay back to back
-          wb[buf][i] = ldg4(w1row + (s << 4));
+          wb[buf][i] = ldg4_w(w1row + (s << 4));
         }
       } else {
 #pragma unroll
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
           const int sub = min(wave + NWV * (SPG * (g - g1) + j), nsub - 1);
           const float* p = w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 4 * kq;
 #pragma unroll
-          for (int st = 0; st < KS2; ++st) wb[buf][KS2 * j + st] = ldg4(p + 16 * st);
+          for (int st = 0; st < KS2; ++st) wb[buf][KS2 * j + st] = ldg4_w(p + 16 * st);
         }
       }
     };

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_bf16w_ker
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int s = min(8 * g + i, ksteps1 - 1);
-          wb[buf][i] = ldg8h(w1row + (s << 5));
+          wb[buf][i] = ldg8h_w(w1row + (s << 5));
         }
       } else {
 #pragma unroll
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_bf16w_ker
           const int sub = min(wave + NWV * (SPG * (g - g1) + j), nsub - 1);
           const bf16_t* p = w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 8 * kq;
 #pragma unroll
-          for (int st = 0; st < KS2; ++st) wb[buf][KS2 * j + st] = ldg8h(p + 32 * st);
+          for (int st = 0; st < KS2; ++st) wb[buf][KS2 * j + st] = ldg8h_w(p + 32 * st);
         }
       }
     };

@@ -64,13 +64,13 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_w8_kernel
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int s = min(8 * g + i, kd1 - 1);          // clamped, not branched
-          wb[buf][i] = ldg16b(w1row + (s << 6));
+          wb[buf][i] = ldg16b_w(w1row + (s << 6));
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int sub = min(wave + NWV * (8 * (g - g1) + j), nsub - 1);
-          wb[buf][j] = ldg16b(w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 16 * kq);
+          wb[buf][j] = ldg16b_w(w2_slice + (size_t)(16 * sub + col) * w2_row_stride + 16 * kq);
           sc2[buf][j] = s2e[16 * sub + col];
         }
       }

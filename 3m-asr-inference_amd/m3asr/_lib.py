@@ -44,7 +44,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
         "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
-        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages")]
+        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages", "fork_embed")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry

@@ -20,7 +20,7 @@ _TORCH_DTYPE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.int32:
 
 
 def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=False, bf16_activations=True, packed_rows=None,
-                   ep_stages=False):
+                   ep_stages=False, fork_embed=None):
     ec = _lib.EngineConfig()
     ec.input_dim, ec.output_dim = cfg.input_dim, cfg.output_dim
     ec.attention_dim, ec.attention_heads, ec.num_blocks = cfg.attention_dim, cfg.attention_heads, cfg.num_blocks
@@ -39,12 +39,13 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.packed_rows = 0 if packed_rows is None else (1 if packed_rows else -1)
     ec.fp8_activations = int(bool(getattr(cfg, "fp8_activations", False)) and cfg.weight_dtype == "fp8")
     ec.ep_stages = int(bool(ep_stages))
+    ec.fork_embed = 0 if fork_embed is None else (1 if fork_embed else -1)
     return ec
 
 
 class Engine:
     def __init__(self, cfg: EncoderConfig, packed, device="cuda:0", fold_pos_proj=True, debug_taps=False,
-                 fuse_route=False, bf16_activations=True, packed_rows=None, max_shapes=8, ep_stages=False):
+                 fuse_route=False, bf16_activations=True, packed_rows=None, max_shapes=8, ep_stages=False, fork_embed=None):
         """packed: output of plan.pack_weights / plan.load_plan (CPU tensors; GEMM weights in cfg.weight_dtype), or the ``weights`` dict of another
         Engine on the same device (several execution contexts sharing one copy of the weights, like TensorRT's
         multiple IExecutionContexts per engine).
@@ -56,7 +57,9 @@ class Engine:
         1 / True = router + top-1 + index in one single-workgroup launch (S <= 256); 2 = split route (embed half of all
         routers in one GEMM per forward, x half as a folded-LayerNorm GEMM, norm_ff applied by the expert kernel).
         ep_stages: build the expert-parallel stage list ("blocks.N.moe_ep.*") although cfg.ep_world_size is 1 -- a one-rank
-        rehearsal of the exchange (m3asr/ep.py); cfg.ep_world_size > 1 always builds it."""
+        rehearsal of the exchange (m3asr/ep.py); cfg.ep_world_size > 1 always builds it.
+        fork_embed: the embed encoder as a second branch of the captured graph beside the main encoder's start (None =
+        automatic: short inputs; True / False force it)."""
         self.lib = _lib.load()
         from .plan import EXPERT_SLICE
         assert self.lib.m3_moe_expert_slice() == EXPERT_SLICE, "plan.EXPERT_SLICE out of sync with libm3asr_hip.so"
@@ -74,7 +77,7 @@ class Engine:
             table[i].dtype = _TORCH_DTYPE[self.weights[n].dtype]
         self.ep_stages = bool(ep_stages) or cfg.ep_world_size > 1
         ec = _engine_config(cfg, fold_pos_proj, debug_taps, int(fuse_route) if not self.ep_stages else 0, bf16_activations, packed_rows,
-                            ep_stages=ep_stages)
+                            ep_stages=ep_stages, fork_embed=fork_embed)
         self.handle = self.lib.m3_engine_create(C.byref(ec), table, len(names))
         if not self.handle:
             raise _lib.M3Error("m3_engine_create failed: " + _lib.last_error())

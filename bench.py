@@ -110,6 +110,9 @@ def parse():
                     help="N > 1 replica runs: exit non-zero when the expert-parallel probe after the headline line fails or times "
                          "out (default: the outcome is recorded in gpurun_out/ep_probe_nN.json and on stderr, exit code 0)")
     ap.add_argument("--latency-iters", type=int, default=100, help="hipEvent-timed single forwards for p50 / p99 (>= 50)")
+    ap.add_argument("--fork-embed", choices=["auto", "on", "off"], default="auto",
+                    help="embed encoder as a second branch of the captured graph beside the main encoder's start (auto: inputs of "
+                         "up to 512 rows)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
     ap.add_argument("--ep-probe-inject-failure", action="store_true",
@@ -356,8 +359,9 @@ def main():
     feat = feat_cpu.to(dev)
     feat_len = torch.from_numpy(lengths.astype(np.int32)).view(1, B).to(dev)
     packed = {"auto": None, "on": True, "off": False}[args.packed_rows]
+    fork = {"auto": None, "on": True, "off": False}[args.fork_embed]
     # the staged-route engine exposes xn / the router stage, which the synthetic-router calibration needs
-    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False, packed_rows=packed)
+    eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=False, packed_rows=packed, fork_embed=fork)
     phase("engine built (plan packed, weights on the device)")
     if args.routing == "balanced":
         eng.bind(feat, feat_len)
@@ -373,11 +377,11 @@ def main():
         torch.cuda.empty_cache()
         phase("H scales calibrated (%.3g .. %.3g)" % (min(h_scales), max(h_scales)))
         fp8_h_scales = [round(float(min(h_scales)), 6), round(float(max(h_scales)), 6)]
-        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=0, packed_rows=packed)
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=0, packed_rows=packed, fork_embed=fork)
     if route:                                # rebuild from the calibrated state_dict
         del eng
         torch.cuda.empty_cache()
-        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed)
+        eng = Engine.from_state_dict(cfg, weights, device=dev, fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed, fork_embed=fork)
     if not ((rank == 0 and world == 1 and not args.no_cpu_baseline) or (world > 1 and not args.no_ep_probe)):
         weights = None
     eng.bind(feat, feat_len)
@@ -388,7 +392,7 @@ def main():
     # extra execution contexts: same weights, own utterance / stream / workspace / graph
     ctxs = [eng]
     for si in range(1, args.streams):
-        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed)
+        c = eng.clone_context(fold_pos_proj=args.fold_pos, fuse_route=route, packed_rows=packed, fork_embed=fork)
         f2 = torch.from_numpy(np.random.default_rng(5000 + 97 * rank + si).random((B, T, cfg.input_dim), dtype=np.float32)).to(dev)
         c.bind(f2, feat_len.clone())
         ctxs.append(c)
@@ -647,7 +651,7 @@ def main():
                           "frames_per_s_one_stream": round(n_frames / (latency_ms * 1e-3), 1), "hip_graph": use_graph,
                           "h_scale_min_max": fp8_h_scales, "kernels_per_forward": eng.num_kernels(), "fold_pos_proj": bool(args.fold_pos),
                           "routing": args.routing, "route_mode": ["staged", "fused", "split"][route],
-                          "packed_rows": bool(B > 1 and eng.packed_rows()),
+                          "packed_rows": bool(B > 1 and eng.packed_rows()), "fork_embed": args.fork_embed,
                           "timed_region": "median of %d repeats of %d forwards" % (len(rep_dt), args.steps),
                           "ms_per_step_repeats": [round(d_ / args.steps * 1e3, 4) for d_ in rep_dt],
                           "profiler_downgraded": downgraded,

@@ -348,6 +348,12 @@ typedef struct m3_engine_config {
   int32_t ep_stages;             /* 1 = build the expert-parallel stage list ("blocks.N.moe_ep.send / .expert / .combine")
                                   * even with ep_world_size <= 1: a one-rank rehearsal of the exchange, the two all-to-alls
                                   * being device copies ("moe_ep.exchange1 / 2" stages).  ep_world_size > 1 always builds it */
+  int32_t fork_embed;            /* the embed encoder is independent of the main encoder until blocks.0's router reads the
+                                  * embedding (conformer_fmoe_..._hier.py:206-215): in the captured hipGraph it runs as a second
+                                  * branch beside the main subsampler and block 0's macaron FFN / attention / conv module, on
+                                  * its own scratch buffers.  0 = automatic (inputs of up to 512 rows: longer batches fill the
+                                  * chip with every kernel), 1 = always, -1 = never.  Stage-wise runs (m3_engine_run) stay one
+                                  * chain; results are identical either way */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

@@ -83,6 +83,32 @@ def test_engine_graph_replay_and_fold_are_bit_identical():
     assert eng2.num_kernels() < eng.num_kernels()
 
 
+@pytest.mark.parametrize("B,wdt", [(1, "f32"), (3, "f32"), (2, "bf16")])
+def test_engine_forked_embed_branch_is_bit_identical(B, wdt):
+    """fork_embed: in the captured graph the embed encoder runs as a second branch beside the main subsampler and block 0 up to
+    its router (own scratch buffers, joined where the embedding is first read).  Same kernels on the same data: the logits
+    equal the one-chain graph's and the eager run's bit for bit, also on packed ragged rows and after replays."""
+    cfg = EncoderConfig(num_blocks=2, embed_blocks=2, weight_dtype=wdt)
+    w = make_weights(cfg, seed=6)
+    T = 206
+    feat = torch.rand(B, T, cfg.input_dim, generator=torch.Generator().manual_seed(B)).cuda()
+    fl = torch.tensor([[T - 37 * i for i in range(B)]], dtype=torch.int32).cuda()
+    chain = Engine.from_state_dict(cfg, w, fork_embed=False)
+    eager = chain(feat, fl).clone()
+    chain.forward(use_graph=True)
+    chain.stream.synchronize()
+    assert torch.equal(chain._bound[2], eager)
+    forked = Engine.from_state_dict(cfg, w, fork_embed=True)
+    assert torch.equal(forked(feat, fl), eager)                       # eager run of the forked plan (one chain, own scratch)
+    for _ in range(3):
+        forked._bound[2].zero_()
+        forked.forward(use_graph=True)
+        forked.stream.synchronize()
+        assert torch.equal(forked._bound[2], eager)
+    assert forked.workspace_size(B, T) > chain.workspace_size(B, T)   # the embed branch's scratch
+    assert forked.num_kernels() == chain.num_kernels()
+
+
 def test_fused_and_staged_route_paths_agree():
     """fuse_route=1 (router + SoftmaxTopK + ScatterMapping in one launch, LayerNorm applied by the expert kernel) vs the
     staged path (router GEMM writes xn, separate gate+index): same routing decisions, logits within fp32 noise."""
