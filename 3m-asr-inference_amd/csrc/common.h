@@ -79,11 +79,13 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-// Weights that a launch reads exactly once (the skinny GEMMs and the B=1 expert kernel stream 1-107 MB of them per launch):
-// non-temporal loads keep them from displacing the activation rows, which every work-group re-reads, in L1 / L2
-// (MI355X_MICROARCH.md: `nt` loads are L2-served, bypass L1).  -DM3_NT_WEIGHTS=0 builds the plain-load variant for A/B runs.
+// Weights that a launch reads exactly once (the skinny GEMMs and the B=1 expert kernel stream 1-107 MB of them per launch).
+// -DM3_NT_WEIGHTS=1 makes these loads non-temporal (L2-served, bypass L1: MI355X_MICROARCH.md).  A/B at configs[1], same device,
+// same process order (profiles/r03_ab_headline.txt): one forward alone 2.377 vs 2.390 ms (-0.5 %), but 187 k vs 207 k frames/s
+// with four execution contexts (-10 %): the four row-tile work-groups that share a weight tile through their XCD's L2 no
+// longer find it there once their timing is skewed by the other contexts.  Off by default.
 #ifndef M3_NT_WEIGHTS
-#define M3_NT_WEIGHTS 1
+#define M3_NT_WEIGHTS 0
 #endif
 __device__ __forceinline__ f32x4 ldg4_w(const float* p) {
 #if M3_NT_WEIGHTS

@@ -269,11 +269,10 @@ struct Plan {
   size_t bytes;
 };
 
-// short inputs only: a long batch fills the chip with every kernel, two concurrent branches would just take turns
-bool use_fork_embed(const m3_engine_config& c, int B, int S) {
-  if (c.fork_embed < 0 || c.debug_taps) return false;
-  return c.fork_embed > 0 || S <= 512;
-}
+// Only on request.  Measured at configs[1] (profiles/r03_ab_headline.txt): one forward alone 2.39 -> 2.33 ms (the ~13 launches
+// of the main encoder's start overlap the embed encoder), but four execution contexts x two branches are eight concurrently
+// active queues, past the four the part runs truly concurrently: 207 k -> 69 k frames/s.
+bool use_fork_embed(const m3_engine_config& c, int B, int S) { return c.fork_embed > 0 && !c.debug_taps; }
 
 // the blocks run on packed rows: B > 1 (or forced), no per-block taps (they are read as (B, T', D)), staged route
 bool use_packed_rows(const m3_engine_config& c, int B) {
@@ -360,7 +359,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
     p.e_glu = cv.take<float>((size_t)S * D);
     p.e_dw = cv.take<float>((size_t)S * D);
     if (p.splitk_bytes) p.e_splitk = cv.take<float>(p.splitk_bytes / sizeof(float));
-    if (p.xpad) {
+    if (use_packed_rows(c, B)) {      // (not `if (p.xpad)`: the sizing pass carves from a null base)
       p.e_xpad = cv.take<float>((size_t)S * D);
       p.e_xbpad = cv.take<uint16_t>((size_t)S * D);
     }

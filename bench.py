@@ -111,8 +111,8 @@ def parse():
                          "out (default: the outcome is recorded in gpurun_out/ep_probe_nN.json and on stderr, exit code 0)")
     ap.add_argument("--latency-iters", type=int, default=100, help="hipEvent-timed single forwards for p50 / p99 (>= 50)")
     ap.add_argument("--fork-embed", choices=["auto", "on", "off"], default="auto",
-                    help="embed encoder as a second branch of the captured graph beside the main encoder's start (auto: inputs of "
-                         "up to 512 rows)")
+                    help="embed encoder as a second branch of the captured graph beside the main encoder's start (auto = off: it "
+                         "shortens one forward by 2.5 %% but eight concurrently active queues collapse the 4-context throughput)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
     ap.add_argument("--ep-probe-inject-failure", action="store_true",
@@ -146,28 +146,30 @@ def balance_router(eng, cpu_weights):
     histogram is reported with the result."""
     names = eng.stage_names()
     first = 0
-    for li in range(eng.cfg.num_blocks):
-        idx = names.index("blocks.%d.moe_router" % li)
-        eng.run_stages(first, idx + 1)
-        eng.stream.synchronize()
-        lens = eng.buffer("lens", torch.int32)
-        Bb = lens.numel()
-        if Bb > 1 and eng.packed_rows():       # packed layout: the real frames are the first row0[B] rows
-            n_real = int(eng.buffer("row0", torch.int32)[Bb])
-            emb, xn = eng.buffer("embed").view(-1, eng.cfg.embed_dim)[:n_real], eng.buffer("xn").view(-1, eng.cfg.attention_dim)[:n_real]
-            mu = torch.cat([emb.mean(0), xn.mean(0)])
-        else:
-            emb, xn = eng.buffer("embed").view(Bb, -1, eng.cfg.embed_dim), eng.buffer("xn").view(Bb, -1, eng.cfg.attention_dim)
-            valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
-            mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
-        w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
-        # (element-wise ops + reductions only: no GEMM / GEMV call, so the process never loads rocBLAS / Tensile code
-        # objects -- see DESIGN.md 6, "the --pmc abort")
-        w -= ((w * mu).sum(1, keepdim=True) * mu) / (mu * mu).sum()
-        eng.run_stages(idx, idx + 1)                                              # logits with the new weights
-        first = idx + 1
-        cpu_weights["blocks.%d.feed_forward.router_weights" % li] = w.t().contiguous().cpu()
-    eng.run_stages(first, len(names))
+    # everything below is issued on the ENGINE'S stream: the router stage must see the new weights (with the element-wise
+    # ops on torch's default stream they raced with it, and the calibrated routers -- hence the experts touched -- differed
+    # from run to run: 21.8 on average under the profiler's serialised dispatch, 25.6 otherwise)
+    with torch.cuda.stream(eng.stream):
+        for li in range(eng.cfg.num_blocks):
+            idx = names.index("blocks.%d.moe_router" % li)
+            eng.run_stages(first, idx + 1)
+            lens = eng.buffer("lens", torch.int32)
+            Bb = lens.numel()
+            if Bb > 1 and eng.packed_rows():       # packed layout: the real frames are the first row0[B] rows
+                n_real = int(eng.buffer("row0", torch.int32)[Bb])
+                emb, xn = eng.buffer("embed").view(-1, eng.cfg.embed_dim)[:n_real], eng.buffer("xn").view(-1, eng.cfg.attention_dim)[:n_real]
+                mu = torch.cat([emb.mean(0), xn.mean(0)])
+            else:
+                emb, xn = eng.buffer("embed").view(Bb, -1, eng.cfg.embed_dim), eng.buffer("xn").view(Bb, -1, eng.cfg.attention_dim)
+                valid = (torch.arange(emb.shape[1], device=lens.device).view(1, -1) < lens.view(-1, 1))   # real (unpadded) frames
+                mu = torch.cat([emb[valid].mean(0), xn[valid].mean(0)])
+            w = eng.weights["blocks.%d.feed_forward.router_weights_t" % li]          # [E, De + D]
+            # (element-wise ops + reductions only: no GEMM / GEMV call, so the process never loads rocBLAS / Tensile code objects)
+            w -= ((w * mu).sum(1, keepdim=True) * mu) / (mu * mu).sum()
+            eng.run_stages(idx, idx + 1)                                              # logits with the new weights
+            first = idx + 1
+            cpu_weights["blocks.%d.feed_forward.router_weights" % li] = w.t().contiguous().cpu()   # (synchronises the stream)
+        eng.run_stages(first, len(names))
     eng.stream.synchronize()
 
 

@@ -351,9 +351,9 @@ typedef struct m3_engine_config {
   int32_t fork_embed;            /* the embed encoder is independent of the main encoder until blocks.0's router reads the
                                   * embedding (conformer_fmoe_..._hier.py:206-215): in the captured hipGraph it runs as a second
                                   * branch beside the main subsampler and block 0's macaron FFN / attention / conv module, on
-                                  * its own scratch buffers.  0 = automatic (inputs of up to 512 rows: longer batches fill the
-                                  * chip with every kernel), 1 = always, -1 = never.  Stage-wise runs (m3_engine_run) stay one
-                                  * chain; results are identical either way */
+                                  * its own scratch buffers.  1 = on, 0 / -1 = off (default: with several execution contexts the
+                                  * extra branch costs more queue concurrency than it saves latency).  Stage-wise
+                                  * runs (m3_engine_run) stay one chain; results are identical either way */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

@@ -68,6 +68,17 @@ PY
       python bench.py --steps 40 --warmup 5 --no-cpu-baseline --profile-stages > $O/stages_cfg1.json 2> $O/stages_cfg1.txt; echo "rc=$?"
       python bench.py $CFG3 --steps 20 --warmup 3 --no-cpu-baseline --profile-stages > $O/stages_cfg3.json 2> $O/stages_cfg3.txt; echo "rc=$?"
       python bench.py $CFG5 --steps 10 --warmup 2 --no-cpu-baseline --profile-stages > $O/stages_cfg5.json 2> $O/stages_cfg5.txt; echo "rc=$?" ;;
+    ab_headline)
+      # A/B of the round-3 headline levers at configs[1], all in this one call on this one device: forked embed branch on / off,
+      # non-temporal weight loads on / off (second library built here with -DM3_NT_WEIGHTS=0)
+      ( cd 3m-asr-inference_amd && make -j16 EXTRA=-DM3_NT_WEIGHTS=0 OBJDIR=build_nt0 LIB=../tools/_ab_nt0.so > /dev/null 2>&1; echo "nt0 build rc=$?" )
+      for rep in 1 2; do
+        for v in base fork_off nt0 nt0_fork_off; do
+          case $v in base) E=""; A="";; fork_off) E=""; A="--fork-embed off";; nt0) E="M3ASR_LIB=$R/tools/_ab_nt0.so"; A="";; nt0_fork_off) E="M3ASR_LIB=$R/tools/_ab_nt0.so"; A="--fork-embed off";; esac
+          env $E python bench.py --steps 200 --warmup 20 --no-cpu-baseline $A > $O/ab_${v}_$rep.json 2> $O/ab_${v}_$rep.err
+          python3 -c "import json,sys; d=json.loads([l for l in open('$O/ab_${v}_$rep.json') if l.startswith('{')][-1]); print('$v rep $rep: value %.0f  one-stream %.4f ms  p50 %.4f' % (d['value'], d['config']['latency_ms_one_stream'], d['forward']['latency_ms']['p50']))"
+        done
+      done ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
