@@ -177,6 +177,13 @@ static int linear_params(const m3_linear_desc* d, GemmParams* out) {
   p.ln_wsum = d->ln_wsum; p.ln_wbeta = d->ln_wbeta;
   p.row_len = d->len; p.rows_per_batch = d->rows_per_batch; p.mask_in = d->mask_in; p.mask_out = d->mask_out;
   p.act = d->act; p.alpha = d->alpha; p.resid = d->resid; p.ldr = d->ldr;
+  M3_REQUIRE((d->a_dtype == M3_F32 || d->a_dtype == M3_BF16) && (d->y_dtype == M3_F32 || d->y_dtype == M3_BF16),
+             "linear: a_dtype / y_dtype must be f32 or bf16");
+  if (d->a_dtype == M3_BF16 || d->y_dtype == M3_BF16 || d->y_copy_bf16)
+    M3_REQUIRE(p.w_bf16 && p.mode == GEMM_A_PLAIN && !p.ln_gamma, "linear: bf16 activations need bf16 weights, plain A, no affine LayerNorm");
+  p.a_bf16 = d->a_dtype == M3_BF16; p.y_bf16 = d->y_dtype == M3_BF16;
+  p.Yb = d->y_copy_bf16; p.ldyb = d->ld_copy; p.Yb_stats = d->y_copy_stats;
+  p.ln_stats = d->ln_stats; p.ln_stat_parts = d->ln_stat_parts;
   *out = p;
   return 0;
 }

@@ -90,6 +90,7 @@ struct m3_engine {
     void* ws = nullptr; size_t ws_bytes = 0;
     float* splitk_ws = nullptr; size_t splitk_bytes = 0;   // partial tiles of the split-K front-end GEMMs (inside ws)
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
+    bool dma = false;   // a16 and the block GEMMs run on the LDS-DMA kernel: every kernel that writes xb also leaves its row statistics
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
     int ep_cap = 0;        // expert parallel: rows per wire chunk this binding was built for (m3_engine_set_ep_capacity)
     // fork_embed: stages [fork_first, fork_mid) = the embed encoder (side branch of the captured graph), [fork_mid, join_at) =
@@ -252,6 +253,7 @@ struct Plan {
   int32_t* lens;
   float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
   void* xb;                             // bf16 copy of the residual stream (16-bit modes, long batches)
+  float* xstats;                        // [S][kXbStatParts][2]: row statistics of xb for the folded-LayerNorm GEMMs (gemm_bf16_dma.hip)
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
   void* moe_ws; size_t moe_ws_bytes;
   float* splitk; size_t splitk_bytes;   // split-K partials of conv2 / subsampling Linear (fp32 plans, short inputs)
@@ -265,7 +267,7 @@ struct Plan {
   // fork_embed: the embed encoder runs on its own graph branch beside the main subsampler and block 0 up to its router
   // (conformer_fmoe_..._hier.py:206-215: embed is needed first by blocks.0's router), so it owns a second set of scratch
   bool fork;
-  float *e_c1, *e_c2, *e_x, *e_h1, *e_qkv, *e_ctx, *e_glu, *e_dw, *e_xpad, *e_splitk; void *e_xb, *e_xbpad;
+  float *e_c1, *e_c2, *e_x, *e_h1, *e_qkv, *e_ctx, *e_glu, *e_dw, *e_xpad, *e_splitk, *e_xstats; void *e_xb, *e_xbpad;
   size_t bytes;
 };
 
@@ -295,6 +297,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   p.x = cv.take<float>((size_t)S * D);
   p.emb = cv.take<float>((size_t)S * D);
   p.xb = cv.take<uint16_t>((size_t)S * D);
+  p.xstats = cv.take<float>((size_t)S * 2 * kXbStatParts);
   p.h1 = cv.take<float>((size_t)S * F);
   p.qkv = cv.take<float>((size_t)S * 3 * D);
   p.pbuf = cv.take<float>((size_t)Tp * D * (c.num_blocks + c.embed_blocks));
@@ -347,12 +350,13 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   }
   p.fork = use_fork_embed(c, B, S);
   p.e_c1 = p.c1; p.e_c2 = p.c2; p.e_x = p.x; p.e_h1 = p.h1; p.e_qkv = p.qkv; p.e_ctx = p.ctx; p.e_glu = p.glu; p.e_dw = p.dw;
-  p.e_xb = p.xb; p.e_xpad = p.xpad; p.e_xbpad = p.xbpad; p.e_splitk = p.splitk;
+  p.e_xb = p.xb; p.e_xpad = p.xpad; p.e_xbpad = p.xbpad; p.e_splitk = p.splitk; p.e_xstats = p.xstats;
   if (p.fork) {
     p.e_c1 = cv.take<float>((size_t)B * T1 * F1 * D);
     p.e_c2 = cv.take<float>((size_t)S * F2 * D);
     p.e_x = cv.take<float>((size_t)S * D);
     p.e_xb = cv.take<uint16_t>((size_t)S * D);
+    p.e_xstats = cv.take<float>((size_t)S * 2 * kXbStatParts);
     p.e_h1 = cv.take<float>((size_t)S * F);
     p.e_qkv = cv.take<float>((size_t)S * 3 * D);
     p.e_ctx = cv.take<float>((size_t)S * D);
@@ -372,7 +376,7 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
 Plan embed_view(const Plan& pl) {
   Plan q = pl;
   q.c1 = pl.e_c1; q.c2 = pl.e_c2; q.x = pl.e_x; q.h1 = pl.e_h1; q.qkv = pl.e_qkv; q.ctx = pl.e_ctx; q.glu = pl.e_glu; q.dw = pl.e_dw;
-  q.xb = pl.e_xb; q.xpad = pl.e_xpad; q.xbpad = pl.e_xbpad; q.splitk = pl.e_splitk;
+  q.xb = pl.e_xb; q.xpad = pl.e_xpad; q.xbpad = pl.e_xbpad; q.splitk = pl.e_splitk; q.xstats = pl.e_xstats;
   return q;
 }
 
@@ -449,6 +453,12 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
       return a16 ? launch_local_gather(xbpad, pad_of, S, D * 2, xb, s) : 0;
     }, stage_info("row_permute_kernel", 1, (double)S * D * (a16 ? 12 : 8) + 4.0 * S, 0.0));
   }
+  if (e->cur.dma) {   // the first block's folded-LayerNorm GEMM takes the row statistics of xb from its producer: here a pass of its own
+    const void* xbv = pl.xb; float* xs = pl.xstats;
+    const int S = B * T2;
+    add_stage(e, pfx + "row_stats", 1, [=](hipStream_t s) { return launch_row_stats_bf16(xbv, S, D, xs, s); },
+              stage_info("row_stats_bf16_kernel", 1, (double)S * D * 2 + 32.0 * S, 3.0 * S * D));
+  }
 }
 
 static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, int D, int F, int H, int K, bool cnn_ln,
@@ -468,8 +478,16 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
   // kernel that writes x) and bf16 h1 / ctx / dw -- because these GEMMs are bound by the traffic of their fp32 A operand
   const bool a16 = e->cur.a16;
   void* xb = pl.xb;
-  auto from_xb = [&](GemmParams& g) { if (a16) { g.A = (const float*)xb; g.a_bf16 = 1; } };
-  auto also_xb = [&](GemmParams& g) { if (a16) { g.Yb = xb; g.ldyb = D; } };
+  const bool dma = e->cur.dma;
+  float* xstats = pl.xstats;
+  auto from_xb = [&](GemmParams& g) {
+    if (a16) { g.A = (const float*)xb; g.a_bf16 = 1; }
+    if (dma) { g.ln_stats = xstats; g.ln_stat_parts = kXbStatParts; }
+  };
+  auto also_xb = [&](GemmParams& g) {
+    if (a16) { g.Yb = xb; g.ldyb = D; }
+    if (dma) g.Yb_stats = xstats;
+  };
   // packed ragged batch: rows [0, P) are the valid frames of all utterances back to back, P = row0[B] on the device;
   // row-wise kernels skip the tiles beyond P, attention and the depthwise conv find their utterance through row0 / pad_of
   const bool packed = e->cur.packed;
@@ -548,7 +566,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     add_gemm(e, pfx + "ffn.w2", h);
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     void* xbo = a16 ? xb : nullptr;
-    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo); },
+    float* xso = dma ? xstats : nullptr;
+    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo, xso); },
               stage_info("layernorm_kernel", 1, (double)S * D * (a16 ? 10 : 8), 8.0 * S * D));
   } else {  // x = LN_final(x + 0.5 * gate * Expert_g(LN(x)))     (positionwise_feed_forward.py:209-265)
     const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
@@ -659,7 +678,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       });
       // local_gather + gate + residual + LayerNorm: token s reads its result at the wire row it was sent from
       add_stage(e, pfx + "moe_ep.combine", 1, [=](hipStream_t s) {
-        return launch_moe_combine(wire_b, 1, map_send, nullptr, gv, nullptr, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
+        return launch_moe_combine(wire_b, 1, map_send, nullptr, gv, nullptr, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
+                                  dma ? xstats : nullptr);
       }, stage_info("moe_combine_kernel", 1, (double)S * D * 12 + (a16 ? 2.0 * S * D : 0.0), (double)S * D * 11));
       e->cur.buffers["ep.wire_a"] = Buf{wire_a, (size_t)R * D * 4};
       e->cur.buffers["ep.wire_b"] = Buf{wire_b, (size_t)R * D * 4};
@@ -700,7 +720,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_w16_rows(wmode_c, mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_w16_slices(wmode_c, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
-      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr);
+      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
+                                dma ? xstats : nullptr);
     }, stage_info("moe_combine_kernel", 1, (double)S * D * 4 * (eslices + 2) + (a16 ? 2.0 * S * D : 0.0), (double)S * D * (eslices + 10)));
     }
     const std::string b = pfx.substr(0, pfx.size() - 1);
@@ -834,6 +855,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_expert_ffn_f32_tiled_kernels()) return rc;
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
+  if (int rc = init_gemm_bf16_dma_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----
@@ -877,6 +899,11 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     t.M = B * Tp; t.N = c.attention_dim; t.K = c.attention_dim; t.w_bf16 = 1;
     e->cur.a16 = c.weight_dtype != M3_F32 && c.bf16_activations >= 0 && !c.debug_taps && c.embed_dim == c.attention_dim &&
                  (c.embed_linear_units % 128) == 0 && (c.hidden_units % 128) == 0 && gemm_bf16w_uses_tiled(t);
+  }
+  {
+    GemmParams t;     // the narrowest block GEMM as the LDS-DMA kernel would see it
+    t.M = B * Tp; t.N = c.attention_dim; t.K = c.attention_dim; t.lda = c.attention_dim; t.w_bf16 = 1; t.a_bf16 = 1;
+    e->cur.dma = e->cur.a16 && c.attention_dim == 128 * kXbStatParts && gemm_bf16w_uses_dma(t);
   }
   e->cur.packed = use_packed_rows(c, B);
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
@@ -953,6 +980,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     g.M = S; g.N = c.output_dim; g.K = D;
     g.ln_wsum = e->out_linear.wsum; g.ln_eps = 1e-12f;       // after_norm is folded into out_linear
     if (e->cur.a16) { g.A = (const float*)pl.xb; g.a_bf16 = 1; }
+    if (e->cur.dma) { g.ln_stats = pl.xstats; g.ln_stat_parts = kXbStatParts; }
     float* lout = logits;
     if (e->cur.packed) {   // packed rows -> packed logits; the (B, T', V) output is filled from them at the end
       lout = pl.lpk;

@@ -382,6 +382,7 @@ static bool gemm_f32_uses_tiled(const GemmParams& p) {
 // which kernel launch_gemm_f32 / the engine's split-K front end will run for this problem (sizes / mode only)
 const char* gemm_kernel_label(const GemmParams& p, bool splitk) {
   if (splitk) return "gemm_f32_splitk_kernel";
+  if (p.w_bf16 && gemm_bf16w_uses_dma(p)) return "gemm_bf16_dma_kernel";
   if (p.w_bf16) return gemm_bf16w_uses_tiled(p) ? "gemm_bf16w_tiled_kernel" : "gemm_bf16w_kernel";
   return gemm_f32_uses_tiled(p) ? "gemm_f32_tiled_kernel" : "gemm_f32_kernel";
 }

@@ -30,6 +30,16 @@ static int tiled_min_rows() {
 
 constexpr int gemm16_group_steps(int MT, int NW) { return NW == 16 ? 2 : (MT == 4 ? 2 : 4); }
 
+// bf16 activations x bf16 weights from this many rows on: the LDS-DMA fed kernel (gemm_bf16_dma.hip); M3_DMA_MIN_ROWS overrides
+static int dma_min_rows() {
+  static const int v = [] {
+    const char* e = getenv("M3_DMA_MIN_ROWS");
+    return e ? atoi(e) : 512;
+  }();
+  return v;
+}
+bool gemm_bf16w_uses_dma(const GemmParams& p) { return p.M >= dma_min_rows() && gemm_bf16_dma_supports(p); }
+
 // long batches: LDS-tiled kernel, when there are enough 64 x 64 tiles to occupy the chip
 bool gemm_bf16w_uses_tiled(const GemmParams& p) {
   const bool glu = p.act == ACT_GLU;
@@ -279,6 +289,7 @@ int launch_gemm_bf16w(const GemmParams& pin, hipStream_t stream) {
   if (ln) M3_REQUIRE(p.mode == GEMM_A_PLAIN && p.K <= 2047, "gemm_bf16w: LayerNorm needs plain A with K < 2048");
   M3_REQUIRE(!(ln && p.mask_in) || p.ln_wbeta, "gemm_bf16w: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm_bf16w: mask needs row_len");
+  if (gemm_bf16w_uses_dma(p)) return launch_gemm_bf16_dma(p, stream);
   if (gemm_bf16w_uses_tiled(p)) return launch_gemm_bf16w_tiled(p, stream);
   M3_REQUIRE(!p.a_bf16 && !p.y_bf16 && p.Yb == nullptr, "gemm_bf16w: bf16 activations are a feature of the tiled kernel");
   const int Nout = glu ? p.N / 2 : p.N;

@@ -1,0 +1,306 @@
+// bf16 x bf16 GEMM for long batches, fed by LDS-DMA:  Y[M,N] = epilogue( A[M,K] . W[N,K]^T ),  A and W both bf16 in memory.
+//
+// Replaces the TensorRT-native matmuls of the reference (TRTAPI++/python/trt_helper/torch_network_helper.py:573-605) for the
+// dense GEMMs of a block once the engine keeps bf16 activation copies (BASELINE.json configs[2] / [4]: 1 k - 5 k live rows).
+// The register-staged kernel of gemm_bf16_tiled.hip spends its time in the staging itself (global load -> VGPR -> convert ->
+// ds_write, one k-step of prefetch: a chain of ~1.3 us loaded round trips); here no operand byte passes through a register
+// on its way to LDS:
+//   * tile 128 x 128 x 64, 4 waves as 2 x 2, 64 x 64 per wave = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16;
+//   * both operands are K-contiguous rows, so ONE staging scheme serves both: a wave instruction
+//     (buffer_load_dwordx4 ... lds, 64 lanes x 16 B = 1 KB) brings 8 rows x 128 B = 8 full lines; LDS keeps plain 128-B rows
+//     whose 16-B chunks are XOR-swizzled by (row >> 1) & 7 -- applied to the per-lane SOURCE address, because LDS-DMA writes
+//     lane-linearly -- which makes every ds_read_b128 of an MFMA fragment conflict-free (checked against the bank rule of
+//     MI355X_MICROARCH.md: 16-lane groups {0-3,12-15,20-27}, ... each cover 16 distinct 16-B slots);
+//   * 2-stage LDS ring (64 KB), the fills of k-step s+1 are issued before the MFMAs of k-step s and waited for (vmcnt(0))
+//     just before the one barrier of the step; two work-groups share a CU, so one computes while the other waits;
+//   * the fills are inline assembly: a buffer_load ... lds that hipcc can see makes it put s_waitcnt vmcnt(0) in front of
+//     every later LDS read, which would serialise fill and compute inside a work-group;
+//   * epilogue through an LDS image of the tile (row-wise 16-B stores), identical in arithmetic to gemm_bf16_tiled.hip:
+//     folded LayerNorm, bias, ReLU / SiLU / GLU, mask, scale, residual, fp32 and / or bf16 outputs.
+// Folded LayerNorm (ln_wsum): the row statistics cannot be taken while staging (nothing passes through registers); they come
+// from p.ln_stats -- per row, `ln_stat_parts` partial (sum, sum of squares) pairs written by whichever kernel produced the
+// bf16 operand (this kernel's own epilogue with p.Yb_stats, moe_combine, layernorm) from exactly the bf16 values it stored.
+#include "common.h"
+#include "kernels.h"
+
+namespace m3 {
+
+namespace {
+constexpr int DBM = 128, DBN = 128, DBK = 64;
+constexpr int kOpBytes = DBM * DBK * 2;             // one operand tile of one stage: 16 KB
+constexpr int kStageBytes = 2 * kOpBytes;           // A tile, then W tile
+constexpr int kCLd = DBN + 4;                       // fp32 elements per row of the epilogue image
+constexpr int kImageBytes = DBM * kCLd * 4;
+constexpr int kDmaLdsBytes = 2 * kStageBytes > kImageBytes ? 2 * kStageBytes : kImageBytes;
+
+// LDS-DMA fill, hidden from hipcc's waitcnt pass (see the header): 64 lanes x 16 B land at lds_addr + 16 lane
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, size_t bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu)),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bytes > 0xffffffffull ? 0xffffffffull : bytes)), 0x00020000u};
+}
+}  // namespace
+
+template <bool GLU, bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dma_lds[];
+  __shared__ float stats[DBM][2];
+  constexpr int MT = 4, NT = 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Nout = GLU ? (p.N >> 1) : p.N;
+  constexpr int OUTW = GLU ? DBN / 2 : DBN;
+  // XCD-aware tile order (as gemm_bf16_tiled.hip): all column tiles of a row tile on one XCD, back to back
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n_tile = slot % p.n_tiles;
+  const int m_tile = (slot / p.n_tiles) * 8 + xcd;
+  const int m0 = m_tile * DBM;
+  if (m_tile >= p.m_tiles || (p.m_dev != nullptr && m0 > *p.m_dev)) return;   // padding of the grid / no live row (packed batch)
+  const int n0 = n_tile * OUTW;
+  auto btile = [&](int nt) { return GLU ? (nt / 2) * (DBN / 2) + wn * (DBN / 4) + 16 * (nt % 2) : wn * (DBN / 2) + 16 * nt; };
+
+  // ---- fill addressing: instruction j (0..3) of this wave carries tile rows 32 wave + 8 j + (lane >> 3); the lane's LDS
+  //      chunk position lane & 7 holds source chunk (lane & 7) ^ ((row >> 1) & 7) ----
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const u32x4 rs_a = make_rsrc(A, ((size_t)(p.M - 1) * p.lda + p.K) * 2);
+  const u32x4 rs_w = make_rsrc(p.W, (size_t)p.N * p.K * 2);
+  unsigned voff_a[4], voff_w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 32 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int m = min(m0 + r, p.M - 1);
+    voff_a[j] = (unsigned)m * (unsigned)p.lda * 2u + 16u * c;
+    const int n = GLU ? (r / (DBN / 2)) * Nout + min(n0 + (r % (DBN / 2)), Nout - 1) : min(n0 + r, p.N - 1);
+    voff_w[j] = (unsigned)n * (unsigned)p.K * 2u + 16u * c;
+  }
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dma_lds);
+  auto issue = [&](int s, int buf) {
+    const unsigned soff = (unsigned)s * (DBK * 2);
+    const unsigned dst = lds0 + (unsigned)buf * kStageBytes + (unsigned)wave * 4096u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(rs_a, voff_a[j], soff, dst + 1024u * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(rs_w, voff_w[j], soff, dst + kOpBytes + 1024u * j);
+  };
+
+  // ---- fragment addressing: lane reads row (lane & 15) of a 16-row block, chunk 4 kb + (lane >> 4), swizzled ----
+  const int frag_off0 = col * 128 + 16 * ((0 + kq) ^ (col >> 1));
+  const int frag_off1 = col * 128 + 16 * ((4 + kq) ^ (col >> 1));
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const unsigned char* a_lds = dma_lds + buf * kStageBytes + (64 * wm) * 128;
+    const unsigned char* b_lds = dma_lds + buf * kStageBytes + kOpBytes;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int fo = kb ? frag_off1 : frag_off0;
+      bf16x8 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(b_lds + btile(nt) * 128 + fo);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_lds + 16 * mt * 128 + fo);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16h(a, b[nt], acc[mt][nt]);
+      }
+    }
+  };
+
+  const int nsteps = p.K / DBK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+    compute(s & 1);
+    // own fills landed + own fragment reads returned, then the step's barrier: stage (s+1)&1 is complete for every wave,
+    // stage s&1 may be overwritten by the fills of step s+2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  // ---- accumulators -> LDS image (the ring is dead: every wave passed the loop's last barrier) ----
+  float* Cs = reinterpret_cast<float*>(dma_lds);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(64 * wm + 16 * mt + 4 * kq + r) * kCLd + btile(nt) + col] = acc[mt][nt][r];
+  if (LN) {   // row statistics of the bf16 operand, summed over the partials its producer left
+    if (tid < DBM) {
+      const int m = min(m0 + tid, p.M - 1);
+      float t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < p.ln_stat_parts; ++q) {
+        t1 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2];
+        t2 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2 + 1];
+      }
+      stats[tid][0] = t1;
+      stats[tid][1] = t2;
+    }
+  }
+  __syncthreads();
+
+  // ---- fp32 epilogue, row-wise: a lane owns 4 consecutive output columns, a wave sweeps rows ----
+  constexpr int LPR = OUTW / 4;                     // lanes per output row (32, GLU 16)
+  constexpr int RPI = 64 / LPR;                     // rows per wave iteration (2, GLU 4)
+  const int c4 = 4 * (lane % LPR);
+  const int n = n0 + c4;
+  float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ne = min(n + e, Nout - 1);
+    bias0[e] = p.bias ? p.bias[ne] : 0.f;
+    bias1[e] = (GLU && p.bias) ? p.bias[ne + Nout] : 0.f;
+    wsum0[e] = LN ? p.ln_wsum[ne] : 0.f;
+    wsum1[e] = (LN && GLU) ? p.ln_wsum[ne + Nout] : 0.f;
+    wbeta0[e] = (LN && p.mask_in) ? p.ln_wbeta[ne] : 0.f;
+    wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
+  }
+  const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
+  for (int it = 0; it < DBM / (4 * RPI); ++it) {
+    const int row = (4 * it + wave) * RPI + lane / LPR;
+    const int m = m0 + row;
+    const bool live = m < p.M && n < Nout;
+    bool pad = false;
+    if (live && (p.mask_in || p.mask_out)) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+    float mean = 0.f, rstd = 1.f;
+    if (LN) {
+      mean = stats[row][0] / (float)p.K;
+      const float var = fmaxf(stats[row][1] / (float)p.K - mean * mean, 0.f);
+      rstd = rsqrtf(var + p.ln_eps);
+    }
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + c4);
+    f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + DBN / 2 + c4);
+    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live && p.resid) {
+      if (vec_ok) {
+        res = ldg4(p.resid + (size_t)m * p.ldr + n);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < Nout) res[e] = p.resid[(size_t)m * p.ldr + n + e];
+      }
+    }
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y0 = v0[e], y1 = v1[e];
+      if (LN) {
+        if (p.mask_in && pad) {
+          y0 = -wbeta0[e];
+          y1 = -wbeta1[e];
+        } else {
+          y0 = rstd * (y0 - mean * wsum0[e]);
+          y1 = rstd * (y1 - mean * wsum1[e]);
+        }
+      }
+      float t = y0 + bias0[e];
+      if (GLU) t = t * sigmoidf(y1 + bias1[e]);
+      if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+      if (p.act == ACT_SILU) t = silu(t);
+      if (p.mask_out && pad) t = 0.f;
+      t *= p.alpha;
+      if (p.resid) t += res[e];
+      y[e] = t;
+    }
+    bf16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (bf16_t)y[e];
+    if (p.Yb_stats != nullptr) {
+      // (sum, sum of squares) of the bf16 values of this row's OUTW columns: one partial per column tile, read back by the
+      // folded-LayerNorm GEMM that consumes Yb.  All lanes take part in the reduction (rows past M contribute nothing).
+      float t1 = 0.f, t2 = 0.f;
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = (n + e < Nout) ? (float)h[e] : 0.f;
+          t1 += f;
+          t2 += f * f;
+        }
+      }
+      t1 += dpp_mov<0xB1>(t1); t2 += dpp_mov<0xB1>(t2);
+      t1 += dpp_mov<0x4E>(t1); t2 += dpp_mov<0x4E>(t2);
+      t1 += dpp_mov<0x141>(t1); t2 += dpp_mov<0x141>(t2);
+      t1 += dpp_mov<0x140>(t1); t2 += dpp_mov<0x140>(t2);
+      if (LPR == 32) {
+        t1 += __shfl_xor(t1, 16, 64);
+        t2 += __shfl_xor(t2, 16, 64);
+      }
+      if (live && (lane % LPR) == 0) {
+        float* d = p.Yb_stats + ((size_t)m * p.n_tiles + n_tile) * 2;
+        d[0] = t1;
+        d[1] = t2;
+      }
+    }
+    if (!live) continue;
+    if (p.Yb != nullptr && n + 3 < Nout)            // bf16 copy for the next GEMM's A operand (besides the fp32 output)
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Yb) + (size_t)m * p.ldyb + n) = h;
+    if (p.y_bf16) {                                 // output itself in bf16 (N % 4 == 0 checked by the launcher)
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
+    } else if (vec_ok) {
+      stg4(p.Y + (size_t)m * p.ldy + n, y);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < Nout) p.Y[(size_t)m * p.ldy + n + e] = y[e];
+    }
+  }
+}
+
+int init_gemm_bf16_dma_kernels() {
+  static bool done = false;
+  if (done) return 0;
+#define M3_DMA_ATTR(G_, L_) \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes))
+  M3_DMA_ATTR(false, false); M3_DMA_ATTR(false, true); M3_DMA_ATTR(true, false); M3_DMA_ATTR(true, true);
+#undef M3_DMA_ATTR
+  done = true;
+  return 0;
+}
+
+// plain row-major bf16 A (no implicit conv, no concat, no grouping), K a multiple of the k-step, folded LayerNorm only with
+// the producer's row statistics at hand
+bool gemm_bf16_dma_supports(const GemmParams& p) {
+  if (!p.w_bf16 || !p.a_bf16 || p.mode != GEMM_A_PLAIN || p.grp_acc != nullptr || p.w_scale != nullptr) return false;
+  if ((p.K % DBK) != 0 || (p.lda & 7) != 0 || p.ln_gamma != nullptr) return false;
+  if (p.ln_wsum != nullptr && p.ln_stats == nullptr) return false;
+  if (((size_t)(p.M - 1) * p.lda + p.K) * 2 >= ((size_t)1 << 32) || (size_t)p.N * p.K * 2 >= ((size_t)1 << 32)) return false;
+  return true;
+}
+
+int gemm_bf16_dma_col_tiles(const GemmParams& p) { return cdiv(p.act == ACT_GLU ? p.N / 2 : p.N, p.act == ACT_GLU ? DBN / 2 : DBN); }
+
+int launch_gemm_bf16_dma(const GemmParams& pin, hipStream_t stream) {
+  GemmParams p = pin;
+  M3_REQUIRE(gemm_bf16_dma_supports(p), "gemm_bf16_dma: unsupported problem (bf16 A and W, plain mode, K %% 64 == 0)");
+  if (int rc = init_gemm_bf16_dma_kernels()) return rc;
+  const bool glu = p.act == ACT_GLU, ln = p.ln_wsum != nullptr;
+  const int Nout = glu ? p.N / 2 : p.N;
+  M3_REQUIRE(!(ln && p.mask_in) || p.ln_wbeta, "gemm_bf16_dma: folded LayerNorm + input mask needs ln_wbeta");
+  if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm_bf16_dma: mask needs row_len");
+  if (p.y_bf16 || p.Yb) M3_REQUIRE((Nout & 3) == 0 && (p.ldy & 3) == 0 && (p.ldyb & 3) == 0, "gemm_bf16_dma: bf16 output needs N %% 4 == 0");
+  p.m_tiles = cdiv(p.M, DBM);
+  p.n_tiles = gemm_bf16_dma_col_tiles(p);
+  dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
+  if (glu && ln) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, dim3(256), kDmaLdsBytes, stream, p);
+  else if (glu) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, dim3(256), kDmaLdsBytes, stream, p);
+  else if (ln) hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, true>), grid, dim3(256), kDmaLdsBytes, stream, p);
+  else hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, dim3(256), kDmaLdsBytes, stream, p);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace m3

@@ -38,6 +38,10 @@ struct GemmParams {
   // bf16 activation copies (16-bit modes, tiled kernel only): A given as bf16 [M][lda], Y written as bf16, and / or an
   // additional bf16 copy Yb of the fp32 output (the residual stream stays fp32, its GEMM consumers read the copy)
   int a_bf16 = 0, y_bf16 = 0; void* Yb = nullptr; int ldyb = 0;
+  // Row statistics of a bf16 operand for the folded LayerNorm of its consumer (gemm_bf16_dma.hip, where nothing passes
+  // through registers while staging): per row kXbStatParts partial (sum, sum of squares) pairs of the bf16 values.
+  // Yb_stats: the kernel that writes Yb also writes its column tile's partial; ln_stats: the LayerNorm GEMM reads them
+  float* Yb_stats = nullptr; const float* ln_stats = nullptr; int ln_stat_parts = 0;
   // packed ragged batches: device-side count of live rows; work-groups whose first row lies beyond it exit (the row AT
   // the count is still computed: it carries the conv module's pad-frame constant, see dwconv_ln_silu_kernel)
   const int32_t* m_dev = nullptr;
@@ -56,6 +60,15 @@ int gemm_f32_splitk_plan(const GemmParams& p, size_t* ws_bytes);   // number of 
 int launch_gemm_f32_splitk(const GemmParams& p, float* ws, size_t ws_bytes, hipStream_t stream);
 int init_gemm_f32_splitk_kernels();
 int init_gemm_bf16_tiled_kernels();
+// bf16 A x bf16 W, LDS-DMA fed 128 x 128 x 64 tiles (gemm_bf16_dma.hip): the dense GEMMs of long batches in the 16-bit modes
+constexpr int kXbStatParts = 4;                          // partial row statistics kept per row of a bf16 activation copy
+bool gemm_bf16_dma_supports(const GemmParams& p);
+int gemm_bf16_dma_col_tiles(const GemmParams& p);
+bool gemm_bf16w_uses_dma(const GemmParams& p);           // the choice launch_gemm_bf16w makes
+int launch_gemm_bf16_dma(const GemmParams& p, hipStream_t stream);
+int init_gemm_bf16_dma_kernels();
+// (sum, sum of squares) of every row of a bf16 matrix -> stats[row][kXbStatParts][2] (total in part 0, zeros elsewhere)
+int launch_row_stats_bf16(const void* xb, int rows, int D, float* stats, hipStream_t stream);
 int init_gemm_f32_tiled_kernels();    // same for the fp32 tiled kernels (gemm_f32_tiled.hip)   // once, outside graph capture (dynamic-LDS opt-in of the tiled kernels)
 
 // ---- MoE indexing / scatter / gather (moe_index.hip) ----
@@ -135,11 +148,11 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream, void* out_bf16 = nullptr);
+                       hipStream_t stream, void* out_bf16 = nullptr, float* out_stats = nullptr);
 
 // ---- row-wise ops (rowops.hip) ----
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream, void* y_bf16 = nullptr);
+                     hipStream_t stream, void* y_bf16 = nullptr, float* y_stats = nullptr);
 int launch_softmax_top1(const float* logits, int ld, const int32_t* row_len, int rows_per_batch, int S, int E,
                         int32_t* idx, float* value, hipStream_t stream);
 int launch_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,

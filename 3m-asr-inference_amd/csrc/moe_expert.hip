@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
                                                           const float* resid, float alpha,
                                                           const float* __restrict__ ln_gamma,
                                                           const float* __restrict__ ln_beta, float ln_eps,
-                                                          float* out, int S, int D, bf16_t* out_b) {
+                                                          float* out, int S, int D, bf16_t* out_b, float* out_stats) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.x * 4 + wave;
   if (s >= S) return;
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
       }
     }
   }
+  float t1 = 0.f, t2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
@@ -341,24 +342,34 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
       if (out_b != nullptr) {                         // bf16 copy of the residual stream for the next GEMMs' A operand
         bf16x4 h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = (bf16_t)v[i][j];
+        for (int j = 0; j < 4; ++j) {
+          h[j] = (bf16_t)v[i][j];
+          const float f = (float)h[j];
+          t1 += f;
+          t2 += f * f;
+        }
         *reinterpret_cast<bf16x4*>(out_b + (size_t)s * D + c) = h;
       }
     }
+  }
+  if (out_stats != nullptr) {      // row statistics of the bf16 copy (kernels.h: Yb_stats): total in part 0, zeros elsewhere
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if (lane < 2 * kXbStatParts) out_stats[(size_t)s * 2 * kXbStatParts + lane] = lane == 0 ? t1 : (lane == 1 ? t2 : 0.f);
   }
 }
 
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream, void* out_bf16) {
+                       hipStream_t stream, void* out_bf16, float* out_stats) {
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "moe_combine: D=%d must be a multiple of 4 (<=2048)", D);
   if (S == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(S, 4));
 #define M3_COMBINE_CASE(NV_)                                                                              \
   hipLaunchKernelGGL((moe_combine_kernel<NV_>), grid, dim3(256), 0, stream, slab, n_slices, mapping,     \
-                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D, (bf16_t*)out_bf16)
+                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D, (bf16_t*)out_bf16, out_stats)
   if (nv <= 1) M3_COMBINE_CASE(1); else if (nv <= 2) M3_COMBINE_CASE(2); else if (nv <= 4) M3_COMBINE_CASE(4); else M3_COMBINE_CASE(8);
 #undef M3_COMBINE_CASE
   M3_LAUNCH_CHECK();

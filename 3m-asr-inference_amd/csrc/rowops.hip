@@ -20,7 +20,7 @@ namespace m3 {
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* y, int rows, int D, bf16_t* yb) {  // y may alias x (row-local)
+                                                        float* y, int rows, int D, bf16_t* yb, float* ystats) {  // y may alias x (row-local)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float t1 = 0.f, t2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
@@ -62,21 +63,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
       if (yb != nullptr) {                            // bf16 copy for the next GEMMs' A operand
         bf16x4 h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[j] = (bf16_t)o[j];
+        for (int j = 0; j < 4; ++j) {
+          h[j] = (bf16_t)o[j];
+          const float f = (float)h[j];
+          t1 += f;
+          t2 += f * f;
+        }
         *reinterpret_cast<bf16x4*>(yb + (size_t)row * D + c) = h;
       }
     }
   }
+  if (ystats != nullptr) {         // row statistics of the bf16 copy (kernels.h: Yb_stats): total in part 0, zeros elsewhere
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if (lane < 2 * kXbStatParts) ystats[(size_t)row * 2 * kXbStatParts + lane] = lane == 0 ? t1 : (lane == 1 ? t2 : 0.f);
+  }
+}
+
+// (sum, sum of squares) of every row of a bf16 matrix (one wave per row): the statistics a folded-LayerNorm GEMM on the
+// LDS-DMA kernel needs when the operand's producer could not leave them (subsampling Linear + row packing)
+__global__ __launch_bounds__(256) void row_stats_bf16_kernel(const bf16_t* __restrict__ xb, int rows, int D, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int c = lane * 8; c < D; c += 512) {
+    const bf16x8 h = ldg8h(xb + (size_t)row * D + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)h[j];
+      t1 += f;
+      t2 += f * f;
+    }
+  }
+  t1 = wave_sum(t1);
+  t2 = wave_sum(t2);
+  if (lane < 2 * kXbStatParts) stats[(size_t)row * 2 * kXbStatParts + lane] = lane == 0 ? t1 : (lane == 1 ? t2 : 0.f);
+}
+int launch_row_stats_bf16(const void* xb, int rows, int D, float* stats, hipStream_t stream) {
+  M3_REQUIRE((D & 7) == 0, "row_stats: D=%d must be a multiple of 8", D);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(row_stats_bf16_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_t*)xb, rows, D, stats);
+  M3_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream, void* y_bf16) {
+                     hipStream_t stream, void* y_bf16, float* y_stats) {
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "layernorm: dim=%d must be a multiple of 4 (<=2048)", D);
   if (rows == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(rows, 4));
 #define M3_LN_CASE(NV_) \
-  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D, (bf16_t*)y_bf16)
+  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D, (bf16_t*)y_bf16, y_stats)
   if (nv <= 1) M3_LN_CASE(1); else if (nv <= 2) M3_LN_CASE(2); else if (nv <= 4) M3_LN_CASE(4); else M3_LN_CASE(8);
 #undef M3_LN_CASE
   M3_LAUNCH_CHECK();

@@ -35,7 +35,9 @@ class LinearDesc(C.Structure):  # m3_linear_desc
                 ("ln_wsum", C.c_void_p), ("ln_wbeta", C.c_void_p),
                 ("len", C.c_void_p), ("rows_per_batch", C.c_int32), ("mask_in", C.c_int32), ("mask_out", C.c_int32),
                 ("act", C.c_int32), ("alpha", C.c_float),
-                ("resid", C.c_void_p), ("ldr", C.c_int32), ("weight_dtype", C.c_int32)]
+                ("resid", C.c_void_p), ("ldr", C.c_int32), ("weight_dtype", C.c_int32),
+                ("a_dtype", C.c_int32), ("y_dtype", C.c_int32), ("y_copy_bf16", C.c_void_p), ("ld_copy", C.c_int32),
+                ("y_copy_stats", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_stat_parts", C.c_int32)]
 
 
 class EngineConfig(C.Structure):  # m3_engine_config

@@ -158,17 +158,33 @@ def softmax_top1(logits, lens=None, rows_per_batch=0):
 
 # ---------------------------------------------------------------------------------------- dense
 def linear(a, w, bias=None, act=_lib.ACT_NONE, a2=None, ln=None, lens=None, rows_per_batch=0, mask_in=False,
-           mask_out=False, alpha=1.0, resid=None, out=None, ln_folded=None, split_k=False):
+           mask_out=False, alpha=1.0, resid=None, out=None, ln_folded=None, split_k=False, out_dtype=torch.float32,
+           copy_bf16=None, copy_stats=None, ln_stats=None):
     """y = resid + alpha * mask_out(act(LN(mask_in(cat[a,a2])) @ w^T + bias)); a (M,K1), w (N,K).
     ln = (gamma, beta, eps): affine LayerNorm prologue.  ln_folded = (wsum, wbeta or None, eps): w / bias already
-    contain the LayerNorm affine (plan.fold_layernorm) and the kernel normalises its output."""
+    contain the LayerNorm affine (plan.fold_layernorm) and the kernel normalises its output.
+    bf16 activation operands (bf16 weights only): `a` may be a bf16 tensor; out_dtype=torch.bfloat16 writes y as bf16;
+    copy_bf16 (M, n_out) bf16 receives an extra bf16 copy of y, copy_stats (M, n_out/128, 2) f32 its per-tile row statistics;
+    ln_stats (M, parts, 2): such statistics of a bf16 `a`, which the folded LayerNorm then uses."""
     lib = _lib.load()
     M, K1 = a.shape
     N, K = w.shape
     n_out = N // 2 if act == _lib.ACT_GLU else N
-    y = out if out is not None else torch.empty(M, n_out, dtype=torch.float32, device=a.device)
+    y = out if out is not None else torch.empty(M, n_out, dtype=out_dtype, device=a.device)
     d = _lib.LinearDesc()
     d.a, d.lda = a.data_ptr(), a.stride(0)
+    assert a.dtype in (torch.float32, torch.bfloat16) and y.dtype in (torch.float32, torch.bfloat16)
+    d.a_dtype = _lib.BF16 if a.dtype == torch.bfloat16 else _lib.F32
+    d.y_dtype = _lib.BF16 if y.dtype == torch.bfloat16 else _lib.F32
+    if copy_bf16 is not None:
+        assert copy_bf16.dtype == torch.bfloat16 and tuple(copy_bf16.shape) == (M, n_out)
+        d.y_copy_bf16, d.ld_copy = copy_bf16.data_ptr(), copy_bf16.stride(0)
+    if copy_stats is not None:
+        assert copy_bf16 is not None and copy_stats.dtype == torch.float32 and copy_stats.is_contiguous()
+        d.y_copy_stats = copy_stats.data_ptr()
+    if ln_stats is not None:
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.shape[0] == M
+        d.ln_stats, d.ln_stat_parts = ln_stats.data_ptr(), ln_stats.shape[1]
     if a2 is not None:
         d.a2, d.lda2, d.k1 = a2.data_ptr(), a2.stride(0), K1
         assert K1 + a2.shape[1] == K

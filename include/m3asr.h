@@ -203,6 +203,18 @@ typedef struct m3_linear_desc {
    * fp32 accumulate and fp32 epilogue (the reference's plugin_data_type = 1, builder_helper.py:47-57; bf16
    * replaces fp16 on CDNA4).  bf16 supports plain A (no a2) and the folded LayerNorm only; K % 32 == 0. */
   int32_t weight_dtype;
+  /* bf16 activation operands (16-bit modes, long batches; what the engine does between the GEMMs of a block):
+   *   a_dtype = M3_BF16: `a` points at bf16 rows (lda in elements, % 8 == 0);  y_dtype = M3_BF16: `y` receives bf16;
+   *   y_copy_bf16: an additional bf16 copy of the fp32 result (ld_copy in elements), e.g. of the residual stream;
+   *   y_copy_stats: with it, per row and per 128-column tile the (sum, sum of squares) of the bf16 values stored
+   *     ([M][N/128][2] floats) -- the row statistics a folded-LayerNorm GEMM needs when its bf16 operand goes to LDS
+   *     without passing through registers (LDS-DMA kernel); ln_stats / ln_stat_parts: such statistics of `a` (their parts
+   *     are summed), required with ln_wsum when a_dtype = M3_BF16 and the LDS-DMA kernel is to be used.
+   * All zero / NULL = fp32 activations as before. */
+  int32_t a_dtype, y_dtype;
+  void* y_copy_bf16; int32_t ld_copy;
+  float* y_copy_stats;
+  const float* ln_stats; int32_t ln_stat_parts;
 } m3_linear_desc;
 int m3_linear(const m3_linear_desc* desc, m3_stream stream);
 /* The same with a caller-owned workspace: deep-K problems with few output tiles (K >= 4096, e.g. the subsampling Linear of

@@ -259,3 +259,78 @@ def test_engine_rejects_dtype_mismatch():
     cfg16 = EncoderConfig.tiny(weight_dtype="bf16")
     with pytest.raises(_lib.M3Error):
         Engine(cfg16, packed)
+
+
+# ---------------------------------------------------------------------------------------------- LDS-DMA fed GEMM
+# gemm_bf16_dma.hip: bf16 A x bf16 W from 512 rows on (what the engine's block GEMMs run on once it keeps bf16 activation
+# copies).  Checked against an fp64 evaluation of exactly its arithmetic: the bf16 operands as they are, exact products,
+# fp32-or-better accumulation, fp32 epilogue.
+def _tile_stats(yb, n_out):
+    """what y_copy_stats must hold: per row and per 128-column tile (sum, sum of squares) of the bf16 values"""
+    parts = (n_out + 127) // 128
+    f = yb.float().cpu().double()
+    out = torch.zeros(f.shape[0], parts, 2, dtype=torch.float64)
+    for q in range(parts):
+        blk = f[:, 128 * q: 128 * (q + 1)]
+        out[:, q, 0], out[:, q, 1] = blk.sum(1), (blk * blk).sum(1)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 512), (1090, 512, 1024), (4480, 1024, 512), (777, 1434, 512), (2000, 1536, 512),
+                                   (640, 512, 4608)])
+def test_linear_bf16_dma_plain_and_residual(M, N, K):
+    a = rnd(M, K, seed=1).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+    b, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    want = a.double() @ w.double().t() + b.double()
+    y = ops.linear(dev(a), dev(w), dev(b))
+    close(y, want, 2e-5, 2e-5)
+    # residual epilogue with scale, SiLU, a bf16 copy of the result and its per-tile row statistics
+    want2 = res.double() + 0.5 * F.silu(want)
+    yb = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    if N % 128 == 0:
+        st = torch.full((M, N // 128, 2), -1.0, device="cuda")
+        y2 = ops.linear(dev(a), dev(w), dev(b), act=_lib.ACT_SILU, alpha=0.5, resid=dev(res), copy_bf16=yb, copy_stats=st)
+        close(y2, want2, 2e-5, 2e-5)
+        assert torch.equal(yb, y2.to(torch.bfloat16))
+        ts = _tile_stats(yb, N)
+        close(st, ts, 1e-5, 1e-4)
+    # bf16 output
+    y3 = ops.linear(dev(a), dev(w), dev(b), out_dtype=torch.bfloat16)
+    assert y3.dtype == torch.bfloat16 and torch.equal(y3, y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,T", [(16, 90), (5, 300)])
+def test_linear_bf16_dma_epilogues(B, T):
+    """GLU + folded LayerNorm from the producer's row statistics + input mask (the conv module's pointwise_conv1), and the
+    output mask (pointwise_conv2) -- the same contracts as the register-staged kernel, on bf16 rows."""
+    M, K, Nh = B * T, 512, 512
+    lens = torch.tensor([T - (7 * i) % T for i in range(B)], dtype=torch.int32)
+    x = (rnd(M, K, seed=1) * 1.5 + 0.3)
+    xb = x.to(torch.bfloat16)
+    ga, be = rnd(K, seed=5, scale=0.3) + 1.0, rnd(K, seed=6, scale=0.2)
+    w, b = rnd(2 * Nh, K, seed=2, scale=K ** -0.5), rnd(2 * Nh, seed=3)
+    wf, bf, wsum, wbeta = fold_layernorm(w, b, ga, be)
+    wf16 = wf.to(torch.bfloat16)
+    wsum16 = wf16.float().sum(1)                       # recomputed from the rounded weights, as plan.cast_gemm_weights does
+    stats = torch.zeros(M, 4, 2)
+    xf = xb.double()
+    for q in range(4):
+        stats[:, q, 0], stats[:, q, 1] = xf[:, 128 * q:128 * (q + 1)].sum(1).float(), (xf[:, 128 * q:128 * (q + 1)] ** 2).sum(1).float()
+    eps = 1e-12
+    y = ops.linear(dev(xb), dev(wf16), dev(bf), act=_lib.ACT_GLU, ln_folded=(dev(wsum16), dev(wbeta), eps), lens=dev(lens),
+                   rows_per_batch=T, mask_in=True, ln_stats=dev(stats))
+    # reference: LayerNorm statistics of the bf16 rows, normalisation on the output side with the rounded weights
+    mean, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    z = ((xf @ wf16.double().t()) - mean * wsum16.double()) / torch.sqrt(var + eps) + bf.double()
+    t = torch.arange(M) % T
+    pad = t >= lens.repeat_interleave(T)
+    z[pad] = (bf.double() - wbeta.double())           # masked_fill(0) after the LayerNorm: the plain bias
+    want = z[:, :Nh] * torch.sigmoid(z[:, Nh:])
+    close(y, want, 2e-3, 2e-3)
+    # output mask + residual
+    w2, b2, res = rnd(Nh, K, seed=7, scale=K ** -0.5).to(torch.bfloat16), rnd(Nh, seed=8), rnd(M, Nh, seed=9)
+    y2 = ops.linear(dev(xb), dev(w2), dev(b2), lens=dev(lens), rows_per_batch=T, mask_out=True, resid=dev(res))
+    want2 = xf @ w2.double().t() + b2.double()
+    want2[pad] = 0.0
+    close(y2, want2 + res.double(), 2e-5, 2e-5)
