@@ -158,6 +158,12 @@ int m3_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int ro
   M3_REQUIRE(wire && gate_recv, "ep_recv_gate: null pointer");
   return launch_ep_recv_gate(wire, world, e_loc, capacity, row_bytes, gate_recv, (hipStream_t)stream);
 }
+int m3_moe_router(const float* embed, int ld_embed, int embed_dim, const float* x, int ldx, int idim, const float* w,
+                  const float* bias, const float* ln_gamma, const float* ln_beta, float ln_eps, float* xn, int ld_xn,
+                  float* logits, int ld_logits, int S, int num_expert, m3_stream stream) {
+  return launch_moe_router(embed, ld_embed, embed_dim, x, ldx, idim, w, bias, ln_gamma, ln_beta, ln_eps, xn, ld_xn, logits,
+                           ld_logits, S, num_expert, nullptr, (hipStream_t)stream);
+}
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,
                     int32_t* idx, float* value, m3_stream stream) {
   return launch_softmax_top1(logits, ld, len, rows_per_batch, S, width, idx, value, (hipStream_t)stream);

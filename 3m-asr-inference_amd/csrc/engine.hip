@@ -11,6 +11,7 @@
 // place by GEMM / combine epilogues; LayerNorms ride in GEMM prologues except where their output is a
 // tensor of its own (MoE input, block output).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -619,7 +620,19 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // LayerNorm(norm_ff) rides in the router GEMM: applied to the x half of cat([embed, x]) and written
     // out once as xn, the expert FFN's input
     r.ln_gamma = ng; r.ln_beta = nb; r.ln_eps = eps; r.ln_on_a2 = 1; r.ln_out = xn; r.ld_ln_out = D;
-    add_gemm(e, pfx + "moe_router", r, true);
+    // from 2048 rows on (A/B at the three BASELINE shapes, one device: configs[4]-share 46.0 -> 29.1 us per layer, forward
+    // 8.83 -> 8.52 ms; configs[2] 14.1 vs 14.9 us and B = 1 +1.5 us per layer: there the 16-column work-groups of gemm.hip
+    // spread the 128-KB weight pull over more CUs).  M3_ROUTER_MIN_ROWS overrides (read once).
+    static const int router_min_rows = [] { const char* ev = getenv("M3_ROUTER_MIN_ROWS"); return ev ? atoi(ev) : 2048; }();
+    if (moe_router_supports(De, D, Etot) && S >= router_min_rows) {
+      // the dedicated kernel: one work-group per 16 rows and all experts, every activation byte read once (moe_router.hip)
+      const float* emb = pl.emb; const float* rw = w.router.w; const float* rb = w.router.b;
+      add_stage(e, pfx + "moe_router", 1, [=](hipStream_t s) {
+        return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn, D, rl, Etot, S, Etot, pdev, s);
+      }, stage_info("moe_router_kernel", 1, (double)Etot * (De + D) * 4 + (double)S * (De + 2 * D + Etot) * 4, 2.0 * S * Etot * (De + D)));
+    } else {
+      add_gemm(e, pfx + "moe_router", r, true);
+    }
     const bool ep = world > 1 || c.ep_stages > 0;
     if (ep) {
       // ---- expert parallel (m3asr/ep.py drives the two all-to-alls between these stages; FastMoE semantics
@@ -856,6 +869,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   if (int rc = init_gemm_bf16_dma_kernels()) return rc;
+  if (int rc = init_moe_router_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----

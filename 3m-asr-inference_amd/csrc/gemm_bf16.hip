@@ -30,11 +30,14 @@ static int tiled_min_rows() {
 
 constexpr int gemm16_group_steps(int MT, int NW) { return NW == 16 ? 2 : (MT == 4 ? 2 : 4); }
 
-// bf16 activations x bf16 weights from this many rows on: the LDS-DMA fed kernel (gemm_bf16_dma.hip); M3_DMA_MIN_ROWS overrides
+// bf16 activations x bf16 weights from this many rows on: the LDS-DMA fed kernel (gemm_bf16_dma.hip).  Measured against the
+// register-staged kernel (tools/bench_gemm_bf16.py --a16, profiles/r03_gemm_dma_vs_staged.txt): +12-16 % at 16 384 rows, +0-16 %
+// at 4 480, SLOWER at 1 984 rows (128 x 128 tiles leave most CUs idle there and a CU keeps only ~16 KB of LDS-DMA in
+// flight: a k-step is a full ~1.3 us round trip).  M3_DMA_MIN_ROWS overrides (read once).
 static int dma_min_rows() {
   static const int v = [] {
     const char* e = getenv("M3_DMA_MIN_ROWS");
-    return e ? atoi(e) : 512;
+    return e ? atoi(e) : 4096;
   }();
   return v;
 }

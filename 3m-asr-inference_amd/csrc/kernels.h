@@ -83,6 +83,13 @@ int launch_moe_route(const float* x, int ldx, int D, const float* wx, const floa
                      const float* eall, int ld_e, float ln_eps, const int32_t* row_len, int rows_per_batch, int S, int E,
                      int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
                      hipStream_t stream);
+// router product on cat([embed, LayerNorm(x)]) with the normalised rows written out (moe_router.hip): one work-group per 16
+// rows and all N <= 64 experts
+bool moe_router_supports(int De, int D, int N);
+int init_moe_router_kernels();
+int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx, int D, const float* W, const float* bias,
+                      const float* gamma, const float* beta, float eps, float* xn, int ldxn, float* Y, int ldy, int M, int N,
+                      const int32_t* m_dev, hipStream_t stream);
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 

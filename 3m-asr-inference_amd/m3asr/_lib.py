@@ -102,6 +102,7 @@ SIGNATURES = {
     "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_moe_combine_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "m3_moe_router": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _i, _vp]),
     "m3_linear": (_i, [_P(LinearDesc), _vp]),
     "m3_linear_workspace_size": (_sz, [_P(LinearDesc)]),
     "m3_linear_ws": (_i, [_P(LinearDesc), _vp, _sz, _vp]),

@@ -144,6 +144,20 @@ def moe_combine(rows, mapping, gate_value=None, resid=None, alpha=1.0, ln=None, 
     return y
 
 
+def moe_router(embed, x, w, ln, bias=None, want_xn=True):
+    """logits (S, E) = cat([embed, LayerNorm(x)]) @ w^T (+ bias), xn = LayerNorm(x); w (E, De + D) fp32, ln = (gamma, beta, eps)."""
+    lib = _lib.load()
+    S, De = embed.shape
+    D = x.shape[1]
+    E = w.shape[0]
+    assert w.shape[1] == De + D and w.is_contiguous() and embed.is_contiguous() and x.is_contiguous()
+    logits = torch.empty(S, E, dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(x) if want_xn else None
+    check(lib.m3_moe_router(_f32(embed), De, De, _f32(x), D, D, _f32(w), _f32(bias), _f32(ln[0]), _f32(ln[1]), float(ln[2]),
+                            _f32(xn), D, _p(logits), E, S, E, _stream()), "m3_moe_router")
+    return logits, xn
+
+
 def softmax_top1(logits, lens=None, rows_per_batch=0):
     lib = _lib.load()
     E = logits.shape[-1]

@@ -172,6 +172,12 @@ int m3_moe_combine_bf16(const float* rows, const int32_t* mapping, const float* 
 int m3_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_histogram, int S, int world, int e_loc,
                    int capacity, int32_t* map_send, void* wire, int row_bytes, m3_stream stream);
 int m3_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv, m3_stream stream);
+/* Router of the MoE feed-forward (positionwise_feed_forward.py:169-180,225 + norm_ff, fmoe_transformer.py:138-141):
+ * logits[S][num_expert] = cat([embed (S, embed_dim), LayerNorm(x) (S, idim)]) . w^T (+ bias), w [num_expert][embed_dim + idim]
+ * fp32 row-major; xn (may be NULL) receives LayerNorm(x), the expert FFN's input.  num_expert <= 64, dims multiples of 64. */
+int m3_moe_router(const float* embed, int ld_embed, int embed_dim, const float* x, int ldx, int idim, const float* w,
+                  const float* bias, const float* ln_gamma, const float* ln_beta, float ln_eps, float* xn, int ld_xn,
+                  float* logits, int ld_logits, int S, int num_expert, m3_stream stream);
 /* Replaces ComputeSoftmaxAndTop1 (softmax_topk_kernel.cu:88-120): logits [S][ld] -> idx[S], value[S];
  * frames t >= len[b] (t = s % rows_per_batch, b = s / rows_per_batch) get idx -1 / value 0; len may be NULL. */
 int m3_softmax_top1(const float* logits, int ld, const int32_t* len, int rows_per_batch, int S, int width,

@@ -227,6 +227,25 @@ def test_linear_concat_router():
     close(y, torch.cat([emb, x], -1) @ wr, 2e-5, 1e-4)
 
 
+@pytest.mark.parametrize("S,E,De,D", [(50, 32, 512, 512), (1, 64, 512, 512), (17, 16, 64, 128), (1090, 32, 512, 512), (4480, 64, 512, 512),
+                                      (333, 48, 256, 1024), (50, 8, 512, 512)])
+def test_moe_router(S, E, De, D):
+    """moe_router.hip: logits = cat([embed, LayerNorm(x)]) @ W_r^T (+ bias) and xn = LayerNorm(x), one work-group per 16 rows
+    and all experts (positionwise_feed_forward.py:169-180,225); offsets make the LayerNorm matter."""
+    emb, x = rnd(S, De, seed=1), rnd(S, D, seed=2) * 1.7 + 0.4
+    wr, b = rnd(E, De + D, seed=3, scale=0.5), rnd(E, seed=4)
+    ga, be = rnd(D, seed=5, scale=0.3) + 1.0, rnd(D, seed=6, scale=0.2)
+    eps = 1e-12
+    want_xn = F.layer_norm(x.double(), (D,), ga.double(), be.double(), eps)
+    want = torch.cat([emb.double(), want_xn], -1) @ wr.double().t()
+    y, xn = ops.moe_router(dev(emb), dev(x), dev(wr), (dev(ga), dev(be), eps))
+    close(xn, want_xn, 2e-5, 2e-5)
+    close(y, want, 2e-5, 2e-4)
+    yb, _ = ops.moe_router(dev(emb), dev(x), dev(wr), (dev(ga), dev(be), eps), bias=dev(b), want_xn=False)
+    close(yb, want + b.double(), 2e-5, 2e-4)
+    assert torch.equal(ops.moe_router(dev(emb), dev(x), dev(wr), (dev(ga), dev(be), eps))[0], y)     # run-to-run: bit for bit
+
+
 # ------------------------------------------------------------------------------------------ expert FFN
 @pytest.mark.parametrize("S,E,D,Fh,mode", [(50, 32, 512, 1024, "uniform"), (50, 32, 512, 1024, "all_one"),
                                            (200, 32, 512, 1024, "uniform"), (1090, 32, 512, 1024, "with_dropped"),
