@@ -23,7 +23,17 @@
 #include "common.h"
 #include "kernels.h"
 
+// -DM3_DMA_DIAG: in-kernel phase stamps (s_memtime) of every work-group into a debug buffer, read back with
+// m3_debug_dma_read (tools/diag_gemm_dma.py); the stamps go nowhere else.  Not part of the product build.
+#ifdef M3_DMA_DIAG
+#define M3_DIAG(...) __VA_ARGS__
+#else
+#define M3_DIAG(...)
+#endif
+
 namespace m3 {
+
+M3_DIAG(__device__ unsigned long long g_dma_dbg[4096 * 8];)
 
 namespace {
 constexpr int DBM = 128, DBN = 128, DBK = 64;
@@ -31,7 +41,7 @@ constexpr int kOpBytes = DBM * DBK * 2;             // one operand tile of one s
 constexpr int kStageBytes = 2 * kOpBytes;           // A tile, then W tile
 constexpr int kCLd = DBN + 4;                       // fp32 elements per row of the epilogue image
 constexpr int kImageBytes = DBM * kCLd * 4;
-constexpr int kDmaLdsBytes = 2 * kStageBytes > kImageBytes ? 2 * kStageBytes : kImageBytes;
+constexpr int dma_lds_bytes(int stages) { return stages * kStageBytes > kImageBytes ? stages * kStageBytes : kImageBytes; }
 
 // LDS-DMA fill, hidden from hipcc's waitcnt pass (see the header): 64 lanes x 16 B land at lds_addr + 16 lane
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -46,11 +56,17 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, size_t bytes) {
 }
 }  // namespace
 
-template <bool GLU, bool LN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams p) {
+// STAGES = 2: 64 KB of LDS, two work-groups per CU (one computes while the other waits for its fills);
+// STAGES = 4: 128 KB, one work-group per CU with three k-steps of fills in flight -- for launches whose work-groups do not
+// outnumber the CUs (nothing else on the CU could cover a fill's ~1300-cycle round trip: measured 1313 cycles per k-step
+// against 512 of MFMA with one step in flight)
+template <bool GLU, bool LN, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dma_lds[];
   __shared__ float stats[DBM][2];
+  __shared__ int rowpad[DBM];
   constexpr int MT = 4, NT = 4;
+  M3_DIAG(unsigned long long dg[8]; dg[0] = __builtin_amdgcn_s_memtime();)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
@@ -62,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
   const int n_tile = slot % p.n_tiles;
   const int m_tile = (slot / p.n_tiles) * 8 + xcd;
   const int m0 = m_tile * DBM;
-  if (m_tile >= p.m_tiles || (p.m_dev != nullptr && m0 > *p.m_dev)) return;   // padding of the grid / no live row (packed batch)
+  if (m_tile >= p.m_tiles) return;                  // padding of the grid
+  // packed ragged batch: the live-row count is a device value; its load is in flight while the fill addresses are formed
+  const int m_live = p.m_dev != nullptr ? *p.m_dev : p.M;
   const int n0 = n_tile * OUTW;
   auto btile = [&](int nt) { return GLU ? (nt / 2) * (DBN / 2) + wn * (DBN / 4) + 16 * (nt % 2) : wn * (DBN / 2) + 16 * nt; };
 
@@ -81,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
     const int n = GLU ? (r / (DBN / 2)) * Nout + min(n0 + (r % (DBN / 2)), Nout - 1) : min(n0 + r, p.N - 1);
     voff_w[j] = (unsigned)n * (unsigned)p.K * 2u + 16u * c;
   }
+  if (m0 > m_live) return;                          // no live row in this tile (the row AT the count is still computed)
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dma_lds);
   auto issue = [&](int s, int buf) {
     const unsigned soff = (unsigned)s * (DBK * 2);
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
   auto compute = [&](int buf) {
     const unsigned char* a_lds = dma_lds + buf * kStageBytes + (64 * wm) * 128;
     const unsigned char* b_lds = dma_lds + buf * kStageBytes + kOpBytes;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int fo = kb ? frag_off1 : frag_off0;
@@ -117,46 +137,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16h(a, b[nt], acc[mt][nt]);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   const int nsteps = p.K / DBK;
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  M3_DIAG(dg[1] = __builtin_amdgcn_s_memtime();)
+  // prologue: STAGES - 1 k-steps of fills in flight, the first one waited for
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+    if (t < nsteps) issue(t, t);
+  if (STAGES == 2 || nsteps == 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (STAGES == 4 && nsteps >= 3) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  M3_DIAG(dg[2] = __builtin_amdgcn_s_memtime();)
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-    compute(s & 1);
-    // own fills landed + own fragment reads returned, then the step's barrier: stage (s+1)&1 is complete for every wave,
-    // stage s&1 may be overwritten by the fills of step s+2
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the stage freed by step s-1 (every wave passed that step's barrier with its fragment reads returned) takes step s+STAGES-1
+    if (s + STAGES - 1 < nsteps) issue(s + STAGES - 1, (s + STAGES - 1) % STAGES);
+    compute(s % STAGES);
+    // own fills of step s+1 landed (8 fills per step and wave stay counted for each later step in flight), own fragment reads
+    // returned, then the step's barrier
+    const int ahead = min(STAGES - 2, nsteps - 2 - s);   // k-steps that may stay in flight beyond step s+1
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
-  // ---- accumulators -> LDS image (the ring is dead: every wave passed the loop's last barrier) ----
-  float* Cs = reinterpret_cast<float*>(dma_lds);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cs[(64 * wm + 16 * mt + 4 * kq + r) * kCLd + btile(nt) + col] = acc[mt][nt][r];
-  if (LN) {   // row statistics of the bf16 operand, summed over the partials its producer left
-    if (tid < DBM) {
-      const int m = min(m0 + tid, p.M - 1);
-      float t1 = 0.f, t2 = 0.f;
-      for (int q = 0; q < p.ln_stat_parts; ++q) {
-        t1 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2];
-        t2 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2 + 1];
-      }
-      stats[tid][0] = t1;
-      stats[tid][1] = t2;
-    }
-  }
-  __syncthreads();
-
-  // ---- fp32 epilogue, row-wise: a lane owns 4 consecutive output columns, a wave sweeps rows ----
+  M3_DIAG(dg[3] = __builtin_amdgcn_s_memtime();)
+  // ---- epilogue.  Measured with in-kernel stamps (tools/diag_gemm_dma.py): the row sweep, not the k-loop, was the longest
+  //      phase (13-19 k cycles of 28-45 k): a load inside the sweep (residual, row length) makes hipcc wait vmcnt(0) in every
+  //      iteration, and vmcnt counts the previous iteration's STORES too, so each iteration paid a full store round trip.
+  //      Now every load of the sweep is issued up front -- residual rows into registers (the accumulators are dead by then),
+  //      row masks into LDS -- and the sweep itself is loads-free: stores stream back to back. ----
   constexpr int LPR = OUTW / 4;                     // lanes per output row (32, GLU 16)
   constexpr int RPI = 64 / LPR;                     // rows per wave iteration (2, GLU 4)
+  constexpr int IT = DBM / (4 * RPI);               // iterations of the sweep (16, GLU 8)
   const int c4 = 4 * (lane % LPR);
   const int n = n0 + c4;
+  // 16-byte row accesses everywhere (every shape of the model but the logits, N = 1434): the unrolled, loads-free sweep;
+  // otherwise a rolled sweep with element-wise accesses (slow path, correctness only)
+  const bool fast = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && ((Nout & 3) == 0);
+  f32x4 res[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.resid && fast) {
+      const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, p.M - 1);       // clamped, never branched around
+      res[it] = ldg4(p.resid + (size_t)m * p.ldr + min(n, Nout - 4));
+    }
+  }
   float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -168,32 +196,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
     wbeta0[e] = (LN && p.mask_in) ? p.ln_wbeta[ne] : 0.f;
     wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
   }
-  const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
-  for (int it = 0; it < DBM / (4 * RPI); ++it) {
+  // accumulators -> LDS image (the ring is dead: every wave passed the loop's last barrier)
+  float* Cs = reinterpret_cast<float*>(dma_lds);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(64 * wm + 16 * mt + 4 * kq + r) * kCLd + btile(nt) + col] = acc[mt][nt][r];
+  if (tid < DBM) {
+    const int m = min(m0 + tid, p.M - 1);
+    if (LN) {   // row statistics of the bf16 operand, summed over the partials its producer left
+      float t1 = 0.f, t2 = 0.f;
+      for (int q = 0; q < p.ln_stat_parts; ++q) {
+        t1 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2];
+        t2 += p.ln_stats[((size_t)m * p.ln_stat_parts + q) * 2 + 1];
+      }
+      const float mean = t1 / (float)p.K;
+      stats[tid][0] = mean;
+      stats[tid][1] = rsqrtf(fmaxf(t2 / (float)p.K - mean * mean, 0.f) + p.ln_eps);
+    }
+    rowpad[tid] = (p.mask_in || p.mask_out) ? ((m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch] ? 1 : 0) : 0;
+  }
+  __syncthreads();
+  M3_DIAG(dg[4] = __builtin_amdgcn_s_memtime();)
+
+  // one row of the sweep; rv = the residual values of this lane's 4 columns
+  auto sweep_row = [&](int it, const f32x4& rv, bool vec) {
     const int row = (4 * it + wave) * RPI + lane / LPR;
     const int m = m0 + row;
     const bool live = m < p.M && n < Nout;
-    bool pad = false;
-    if (live && (p.mask_in || p.mask_out)) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+    const bool pad = rowpad[row] != 0;
     float mean = 0.f, rstd = 1.f;
     if (LN) {
-      mean = stats[row][0] / (float)p.K;
-      const float var = fmaxf(stats[row][1] / (float)p.K - mean * mean, 0.f);
-      rstd = rsqrtf(var + p.ln_eps);
+      mean = stats[row][0];
+      rstd = stats[row][1];
     }
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + c4);
     f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + DBN / 2 + c4);
-    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (live && p.resid) {
-      if (vec_ok) {
-        res = ldg4(p.resid + (size_t)m * p.ldr + n);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < Nout) res[e] = p.resid[(size_t)m * p.ldr + n + e];
-      }
-    }
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -213,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
       if (p.act == ACT_SILU) t = silu(t);
       if (p.mask_out && pad) t = 0.f;
       t *= p.alpha;
-      if (p.resid) t += res[e];
+      if (p.resid) t += rv[e];
       y[e] = t;
     }
     bf16x4 h;
@@ -245,26 +286,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const GemmParams 
         d[1] = t2;
       }
     }
-    if (!live) continue;
-    if (p.Yb != nullptr && n + 3 < Nout)            // bf16 copy for the next GEMM's A operand (besides the fp32 output)
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Yb) + (size_t)m * p.ldyb + n) = h;
-    if (p.y_bf16) {                                 // output itself in bf16 (N % 4 == 0 checked by the launcher)
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
-    } else if (vec_ok) {
-      stg4(p.Y + (size_t)m * p.ldy + n, y);
-    } else {
+    if (live) {
+      if (vec) {
+        if (p.Yb != nullptr)                        // bf16 copy for the next GEMM's A operand (besides the fp32 output)
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Yb) + (size_t)m * p.ldyb + n) = h;
+        if (p.y_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
+        else stg4(p.Y + (size_t)m * p.ldy + n, y);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < Nout) p.Y[(size_t)m * p.ldy + n + e] = y[e];
+        for (int e = 0; e < 4; ++e)
+          if (n + e < Nout) p.Y[(size_t)m * p.ldy + n + e] = y[e];
+      }
+    }
+  };
+  if (fast) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) sweep_row(it, res[it], true);
+  } else {
+    for (int it = 0; it < IT; ++it) {               // fp32 output only (the launcher rejects bf16 outputs with N % 4 != 0)
+      f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, p.M - 1);
+      if (p.resid)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
+      sweep_row(it, rv, false);
     }
   }
+  M3_DIAG(dg[5] = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          dg[6] = __builtin_amdgcn_s_memtime();
+          if (lane == 0 && wave == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = g_dma_dbg + (size_t)blockIdx.x * 8;
+            for (int i = 0; i < 7; ++i) o[i] = dg[i];
+            o[7] = __builtin_amdgcn_s_memrealtime();
+          })
 }
 
 int init_gemm_bf16_dma_kernels() {
   static bool done = false;
   if (done) return 0;
-#define M3_DMA_ATTR(G_, L_) \
-  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes))
+#define M3_DMA_ATTR(G_, L_)                                                                                                     \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(2))); \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(4)))
   M3_DMA_ATTR(false, false); M3_DMA_ATTR(false, true); M3_DMA_ATTR(true, false); M3_DMA_ATTR(true, true);
 #undef M3_DMA_ATTR
   done = true;
@@ -295,12 +358,31 @@ int launch_gemm_bf16_dma(const GemmParams& pin, hipStream_t stream) {
   p.m_tiles = cdiv(p.M, DBM);
   p.n_tiles = gemm_bf16_dma_col_tiles(p);
   dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
-  if (glu && ln) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, dim3(256), kDmaLdsBytes, stream, p);
-  else if (glu) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, dim3(256), kDmaLdsBytes, stream, p);
-  else if (ln) hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, true>), grid, dim3(256), kDmaLdsBytes, stream, p);
-  else hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, dim3(256), kDmaLdsBytes, stream, p);
+  // work-groups that do not outnumber the CUs: one per CU with a 4-stage ring; else two per CU with 2 stages each
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+  }();
+  const bool deep = (long)p.m_tiles * p.n_tiles <= cus && p.K / DBK >= 4;
+#define M3_DMA_LAUNCH(G_, L_)                                                                                              \
+  do {                                                                                                                     \
+    if (deep) hipLaunchKernelGGL((gemm_bf16_dma_kernel<G_, L_, 4>), grid, dim3(256), dma_lds_bytes(4), stream, p);         \
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<G_, L_, 2>), grid, dim3(256), dma_lds_bytes(2), stream, p);              \
+  } while (0)
+  if (glu && ln) M3_DMA_LAUNCH(true, true);
+  else if (glu) M3_DMA_LAUNCH(true, false);
+  else if (ln) M3_DMA_LAUNCH(false, true);
+  else M3_DMA_LAUNCH(false, false);
+#undef M3_DMA_LAUNCH
   M3_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace m3
+
+#ifdef M3_DMA_DIAG
+extern "C" int m3_debug_dma_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(m3::g_dma_dbg), bytes < sizeof(m3::g_dma_dbg) ? bytes : sizeof(m3::g_dma_dbg));
+}
+#endif

@@ -315,12 +315,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
   }
   const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
-  for (int it = 0; it < TBM / (4 * RPI); ++it) {
+  // Every load of the sweep is issued BEFORE it (residual rows into registers -- the accumulators are dead --, the row
+  // masks resolved here): a load inside the sweep makes hipcc wait vmcnt(0) in every iteration, and vmcnt counts the
+  // previous iteration's stores too, so each iteration paid a full store round trip (in-kernel stamps of the LDS-DMA
+  // kernel, tools/diag_gemm_dma.py: the sweep was the longest phase of the work-group).
+  constexpr int IT = TBM / (4 * RPI);
+  f32x4 res_all[IT];
+  bool pad_all[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, m_end - 1);      // clamped, never branched around
+    res_all[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.resid) {
+      if (vec_ok) {
+        res_all[it] = ldg4(p.resid + (size_t)m * p.ldr + n);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res_all[it][e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
+      }
+    }
+    pad_all[it] = (p.mask_in || p.mask_out) ? ((m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch]) : false;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
     const int row = (4 * it + wave) * RPI + lane / LPR;
     const int m = m0 + row;
     if (m >= m_end || n >= Nout) continue;
-    bool pad = false;
-    if (p.mask_in || p.mask_out) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+    const bool pad = pad_all[it];
     float mean = 0.f, rstd = 1.f;
     if (LN) {
       mean = stats[row][0] / (float)p.K;
@@ -330,16 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4);
     f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + TBN / 2 + c4);
-    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.resid) {
-      if (vec_ok) {
-        res = ldg4(p.resid + (size_t)m * p.ldr + n);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < Nout) res[e] = p.resid[(size_t)m * p.ldr + n + e];
-      }
-    }
+    const f32x4 res = res_all[it];
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -442,6 +454,9 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
   // latency / throughput trade, off by default
   static const int thin_below = [] { const char* e = getenv("M3_TILED_THIN_BELOW"); return e ? atoi(e) : 0; }();
   const bool thin = !big && !conv && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < thin_below;
+  // (k-steps of 256 with one work-group per CU were tried for launches of <= 256 tiles: half the round trips, but 13.2 vs
+  //  9.0 us at 1090 x 1024 x 512 and 4.39 vs 3.95 ms per configs[2] forward -- two resident work-groups that overlap each
+  //  other's waits are worth more than fewer, longer steps)
   const int bm = big ? 128 : (thin ? 32 : 64), bn = big ? 128 : 64;
   p.m_tiles = cdiv(p.M, bm);
   p.n_tiles = glu ? cdiv(Nout, bn / 2) : cdiv(p.N, bn);
@@ -456,7 +471,7 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
     else if (big)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>), grid, dim3(256),                    \
                          tiled_lds_bytes(128, 128, 64), stream, p);                                                  \
-    else if (thin && p.a_bf16) {                                                                                     \
+    else if (thin && p.a_bf16) {                                                                                   \
       if constexpr (!C_)                                                                                             \
         hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<32, 64, 128, G_, false, L_, 0, false, true>), grid, dim3(256),   \
                            tiled_lds_bytes(32, 64, 128), stream, p);                                                 \

@@ -202,12 +202,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const GemmParams
     wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
   }
   const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
-  for (int it = 0; it < TBM / (4 * RPI); ++it) {
+  // Every load of the sweep is issued BEFORE it (residual rows into registers -- the accumulators are dead --, the row
+  // masks resolved here): a load inside the sweep makes hipcc wait vmcnt(0) in every iteration, and vmcnt counts the
+  // previous iteration's stores too, so each iteration paid a full store round trip (in-kernel stamps of the LDS-DMA
+  // kernel, tools/diag_gemm_dma.py: the sweep was the longest phase of the work-group).
+  constexpr int IT = TBM / (4 * RPI);
+  f32x4 res_all[IT];
+  bool pad_all[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, m_end - 1);      // clamped, never branched around
+    res_all[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.resid) {
+      if (vec_ok) {
+        res_all[it] = ldg4(p.resid + (size_t)m * p.ldr + n);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res_all[it][e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
+      }
+    }
+    pad_all[it] = (p.mask_in || p.mask_out) ? ((m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch]) : false;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
     const int row = (4 * it + wave) * RPI + lane / LPR;
     const int m = m0 + row;
     if (m >= m_end || n >= Nout) continue;
-    bool pad = false;
-    if (p.mask_in || p.mask_out) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+    const bool pad = pad_all[it];
     float mean = 0.f, rstd = 1.f;
     if (LN) {
       mean = stats[row][0] / (float)p.K;
@@ -217,16 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const GemmParams
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4);
     f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + TBN / 2 + c4);
-    f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.resid) {
-      if (vec_ok) {
-        res = ldg4(p.resid + (size_t)m * p.ldr + n);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < Nout) res[e] = p.resid[(size_t)m * p.ldr + n + e];
-      }
-    }
+    const f32x4 res = res_all[it];
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
