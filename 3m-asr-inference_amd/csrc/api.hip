@@ -223,6 +223,10 @@ int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, cons
   return launch_relpos_attention(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo,
                                  (hipStream_t)stream);
 }
+int m3_relpos_attention_bf16(const void* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
+                             const int32_t* len, int B, int T, int H, int dk, float scale, void* out, int ldo, m3_stream stream) {
+  return launch_relpos_attention_bf16(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo, (hipStream_t)stream);
+}
 int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
                       float eps, int B, int T, int D, int K, float* out, m3_stream stream) {
   return launch_dwconv_ln_silu(z, w_kc, bias, gamma, beta, eps, B, T, D, K, out, (hipStream_t)stream);

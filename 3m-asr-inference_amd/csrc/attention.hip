@@ -185,4 +185,220 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same operator on bf16 rows for the 16-bit modes of long batches (qkv written as bf16 by the QKV GEMM, context
+// written as bf16 for the output projection), T' <= 128 keys:  v_mfma_f32_16x16x32_bf16, fp32 softmax.
+//
+// One work-group per (utterance, head) instead of one per (utterance, head, 16-query tile): K, P = linear_pos(pos_emb) and
+// V of the head are staged ONCE into LDS (full-line loads; the fp32 kernel above re-reads them per query tile and loads V
+// with 4-byte accesses), then each wave takes query tiles.  Scores are computed TRANSPOSED, S^T = K (q+u)^T + P (q+v)^T
+// (keys on the MFMA row axis): a lane then holds, for ITS query (column), 4 consecutive keys per 16-key tile in registers --
+// the whole row of probabilities for T' <= 128 is 32 registers, softmax needs no online rescaling and no LDS transpose, and
+// two key tiles packed together ARE the B operand of  O^T = V^T P^T  (k index j < 4: tile 2c key 4kq+j, j >= 4: tile 2c+1);
+// V is kept transposed in LDS ([channel][key]) so that the matching A operand is two 8-byte reads.
+namespace {
+constexpr int kAttTP = 128;                                    // keys a work-group can hold
+template <int DK> constexpr int att16_lds_bytes() { return 2 * kAttTP * (DK + 8) * 2 + DK * (kAttTP + 8) * 2; }
+}  // namespace
+
+template <int DK>
+__global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t* __restrict__ qkv, int ldq,
+                                                                   const float* __restrict__ pmat, int ldp,
+                                                                   const float* __restrict__ pos_u,
+                                                                   const float* __restrict__ pos_v,
+                                                                   const int32_t* __restrict__ row_len, int T, int D, int H,
+                                                                   float scale, bf16_t* __restrict__ out, int ldo,
+                                                                   const int32_t* __restrict__ row0) {
+  constexpr int KLD = DK + 8;                                  // bf16 elements per K / P row in LDS (conflict-free 16-B fragment reads)
+  constexpr int VLD = kAttTP + 8;                              // bf16 elements per Vt row (one channel, all keys)
+  constexpr int KS = DK / 32;                                  // 32-deep k-steps of the score products
+  constexpr int NCH = DK / 16;                                 // 16-channel tiles of the output
+  extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(att_lds);             // [kAttTP][KLD]
+  bf16_t* Ps = Ks + kAttTP * KLD;                              // [kAttTP][KLD]
+  bf16_t* Vt = Ps + kAttTP * KLD;                              // [DK][VLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int len = min(row_len ? row_len[b] : T, T);
+  if (len <= 0) return;
+  const size_t brow = row0 ? (size_t)row0[b] : (size_t)b * T;
+  const int q_end = row0 ? len : T;                            // query rows this utterance owns (padded layout: all T)
+  const int nkt = (len + 15) >> 4;                             // 16-key tiles with at least one valid key
+  const int nk32 = ((len + 31) >> 5) << 5;                     // keys rounded up to the pairs the P.V product consumes
+
+  // ---- all loads of the work-group are issued up front, clamped instead of branched (a load under a branch is one memory
+  //      round trip per loop iteration): the query rows of this wave's (at most two) tiles, then K / P / V of the head ----
+  constexpr int QT = kAttTP / 64;                              // query tiles per wave
+  bf16x8 q8[QT][KS];
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    const int qi = min(16 * wave + 64 * i + col, q_end - 1);
+    const bf16_t* qrow = qkv + (brow + qi) * ldq + h * DK + 8 * kq;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) q8[i][s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
+  }
+  f32x4 pu[KS][2], pv[KS][2];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    pu[s][0] = ldg4(pos_u + h * DK + 32 * s + 8 * kq);
+    pu[s][1] = ldg4(pos_u + h * DK + 32 * s + 8 * kq + 4);
+    pv[s][0] = ldg4(pos_v + h * DK + 32 * s + 8 * kq);
+    pv[s][1] = ldg4(pos_v + h * DK + 32 * s + 8 * kq + 4);
+  }
+  {
+    constexpr int CPR = DK / 8;                                // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;                             // rows per pass
+    constexpr int NP = kAttTP / RPP;                           // passes over the key rows
+    const int c = tid % CPR, r0 = tid / CPR;
+    u32x4 kv[NP], vv[NP];
+    f32x4 p0[NP], p1[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int j = min(r0 + RPP * i, len - 1);                // keys >= len: a valid row is read and replaced by zeros below
+      const bf16_t* rowp = qkv + (brow + j) * ldq + h * DK + 8 * c;
+      kv[i] = *reinterpret_cast<const u32x4*>(rowp + D);
+      vv[i] = *reinterpret_cast<const u32x4*>(rowp + 2 * D);
+      const float* pr = pmat + (size_t)j * ldp + h * DK + 8 * c;
+      p0[i] = ldg4(pr);
+      p1[i] = ldg4(pr + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int j = r0 + RPP * i;
+      if (j < nk32) {
+        const bool on = j < len;
+        *reinterpret_cast<u32x4*>(Ks + j * KLD + 8 * c) = on ? kv[i] : u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<bf16x8*>(Ps + j * KLD + 8 * c) = cvt8(on ? p0[i] : f32x4{0.f, 0.f, 0.f, 0.f}, on ? p1[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+        const bf16x8 v8 = __builtin_bit_cast(bf16x8, on ? vv[i] : u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(8 * c + e) * VLD + j] = v8[e];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- query tiles: wave w takes tiles w and w + 4 ----
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    const int q0 = 16 * wave + 64 * i;
+    if (q0 >= q_end) break;
+    bf16x8 qu[KS], qv[KS];                                     // B operands: (q + u)^T, (q + v)^T -- lane (query col, k = 8 kq + j)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qu[s][j] = (bf16_t)((float)q8[i][s][j] + pu[s][0][j]);
+        qu[s][4 + j] = (bf16_t)((float)q8[i][s][4 + j] + pu[s][1][j]);
+        qv[s][j] = (bf16_t)((float)q8[i][s][j] + pv[s][0][j]);
+        qv[s][4 + j] = (bf16_t)((float)q8[i][s][4 + j] + pv[s][1][j]);
+      }
+    }
+    // scores, transposed: sT[t][r] = s(query col, key 16 t + 4 kq + r)
+    f32x4 sT[kAttTP / 16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < kAttTP / 16; ++t) {
+      sT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nkt) {
+        const bf16_t* krow = Ks + (16 * t + col) * KLD + 8 * kq;
+        const bf16_t* prow = Ps + (16 * t + col) * KLD + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          sT[t] = mfma16h(*reinterpret_cast<const bf16x8*>(krow + 32 * s), qu[s], sT[t]);
+          sT[t] = mfma16h(*reinterpret_cast<const bf16x8*>(prow + 32 * s), qv[s], sT[t]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = (16 * t + 4 * kq + r) < len;
+        sT[t][r] = valid ? sT[t][r] * scale : -INFINITY;
+        mx = fmaxf(mx, sT[t][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                    // the four key quarters of this query's column
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < kAttTP / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sT[t][r] = __expf(sT[t][r] - mx);                      // masked keys: exp(-inf) = 0 (len >= 1: mx is finite)
+        sum += sT[t][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    // O^T = V^T P^T over pairs of key tiles
+    f32x4 oT[NCH];
+#pragma unroll
+    for (int n = 0; n < NCH; ++n) oT[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c2 = 0; c2 < kAttTP / 32; ++c2) {
+      if (2 * c2 < nkt) {
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pb[j] = (bf16_t)sT[2 * c2][j];
+          pb[4 + j] = (bf16_t)sT[2 * c2 + 1][j];
+        }
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+          const bf16_t* vrow = Vt + (16 * n + col) * VLD + 32 * c2 + 4 * kq;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow), hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+          bf16x8 va;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            va[j] = lo[j];
+            va[4 + j] = hi[j];
+          }
+          oT[n] = mfma16h(va, pb, oT[n]);
+        }
+      }
+    }
+    // oT[n][r] = O(query col, channel 16 n + 4 kq + r): 4 consecutive channels per lane
+    const int qrow_out = q0 + col;
+    if (qrow_out < q_end) {
+      bf16_t* orow = out + (brow + qrow_out) * ldo + h * DK + 4 * kq;
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        bf16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = (bf16_t)(oT[n][r] * inv);
+        *reinterpret_cast<bf16x4*>(orow + 16 * n) = o4;
+      }
+    }
+  }
+}
+
+bool relpos_attention_bf16_supports(int T, int dk) { return T <= kAttTP && (dk == 64 || dk == 128); }
+
+int init_relpos_attention_bf16_kernels() {
+  static bool done = false;
+  if (done) return 0;
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)relpos_attention_bf16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, att16_lds_bytes<64>()));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)relpos_attention_bf16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, att16_lds_bytes<128>()));
+  done = true;
+  return 0;
+}
+
+int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, int ldp, const float* pos_u, const float* pos_v,
+                                 const int32_t* row_len, int B, int T, int H, int dk, float scale, void* out, int ldo,
+                                 hipStream_t stream, const int32_t* row0) {
+  M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
+  M3_REQUIRE(relpos_attention_bf16_supports(T, dk), "attention (bf16 rows): T'=%d > %d keys or d_k=%d not 64 / 128", T, kAttTP, dk);
+  M3_REQUIRE((ldq & 7) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, "attention (bf16 rows): row strides must be multiples of 8 / 4 / 4");
+  if (int rc = init_relpos_attention_bf16_kernels()) return rc;
+  const int D = H * dk;
+  if (dk == 64)
+    hipLaunchKernelGGL((relpos_attention_bf16_kernel<64>), dim3(B * H), dim3(256), att16_lds_bytes<64>(), stream, (const bf16_t*)qkv,
+                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0);
+  else
+    hipLaunchKernelGGL((relpos_attention_bf16_kernel<128>), dim3(B * H), dim3(256), att16_lds_bytes<128>(), stream, (const bf16_t*)qkv,
+                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace m3

@@ -515,6 +515,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     g.A = x; g.lda = D; g.W = w.qkv.w; g.bias = w.qkv.b; g.Y = pl.qkv; g.ldy = 3 * D; g.M = S; g.N = 3 * D; g.K = D;
     g.ln_wsum = w.qkv.wsum; g.ln_eps = eps;                  // norm_mha is folded into the qkv weight
     from_xb(g);
+    // 16-bit modes, long batches, T' <= 128: q | k | v are written as bf16 and the attention core runs on bf16 MFMAs with
+    // K / P / V of a head staged once per (utterance, head) (attention.hip, second kernel)
+    const bool att16 = a16 && relpos_attention_bf16_supports(Tp, D / H);
+    g.y_bf16 = att16;
     add_gemm(e, pfx + "att.qkv", g);
     // p = linear_pos(pos_emb) of all blocks comes from ONE GEMM per forward ("pos_all" stage):
     // block i's slice is columns [i*D, (i+1)*D) of pbuf [T'][n_blocks*D]
@@ -525,8 +529,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
+      if (att16) return launch_relpos_attention_bf16(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, row0);
       return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0);
-    }, stage_info("relpos_attention_kernel", 1, (double)S * D * (12 + (a16 ? 2 : 4)) + (double)Tp * D * 4, 6.0 * Tp * D * S));
+    }, stage_info(att16 ? "relpos_attention_bf16_kernel" : "relpos_attention_kernel", 1,
+                  (double)S * D * (att16 ? 8 : (12 + (a16 ? 2 : 4))) + (double)Tp * D * 4, 6.0 * Tp * D * S));
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
     o.resid = x; o.ldr = D;
@@ -870,6 +876,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   if (int rc = init_gemm_bf16_dma_kernels()) return rc;
   if (int rc = init_moe_router_kernels()) return rc;
+  if (int rc = init_relpos_attention_bf16_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----

@@ -187,6 +187,13 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
                             float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr);
 
+// the same on bf16 rows (16-bit modes, T' <= 128): qkv bf16 [B*T][ldq], out bf16; one work-group per (utterance, head)
+bool relpos_attention_bf16_supports(int T, int dk);
+int init_relpos_attention_bf16_kernels();
+int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, int ldp, const float* pos_u, const float* pos_v,
+                                 const int32_t* row_len, int B, int T, int H, int dk, float scale, void* out, int ldo,
+                                 hipStream_t stream, const int32_t* row0 = nullptr);
+
 // ---- conv module / subsampling (conv.hip) ----
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream,

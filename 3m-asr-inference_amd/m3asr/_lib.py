@@ -110,6 +110,7 @@ SIGNATURES = {
     "m3_conv2d_3x3s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m3_layer_norm": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_relpos_attention": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "m3_relpos_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "m3_dwconv_ln_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "m3_subsample_conv1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "m3_subsample_conv1_cmvn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -249,6 +249,17 @@ def relpos_attention(qkv, p, pos_u, pos_v, lens, B, T, H, dk):
     return out
 
 
+def relpos_attention_bf16(qkv, p, pos_u, pos_v, lens, B, T, H, dk):
+    """the same on bf16 rows: qkv (B*T, 3*H*dk) bf16 -> ctx (B*T, H*dk) bf16 (T <= 128)"""
+    lib = _lib.load()
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+    D = H * dk
+    out = torch.empty(B * T, D, dtype=torch.bfloat16, device=qkv.device)
+    check(lib.m3_relpos_attention_bf16(_p(qkv), 3 * D, _f32(p), p.stride(0), _f32(pos_u), _f32(pos_v), _i32(lens), B, T, H, dk,
+                                       1.0 / math.sqrt(dk), _p(out), D, _stream()), "m3_relpos_attention_bf16")
+    return out
+
+
 def dwconv_ln_silu(z, w_kc, bias, gamma, beta, eps, B, T):
     lib = _lib.load()
     K, D = w_kc.shape

@@ -237,6 +237,10 @@ int m3_layer_norm(const float* x, const float* gamma, const float* beta, float e
 int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, const float* pos_u,
                         const float* pos_v, const int32_t* len, int B, int T, int H, int dk, float scale,
                         float* out, int ldo, m3_stream stream);
+/* The same operator on bf16 rows (16-bit modes of long batches): qkv and out are bf16 ([B*T][ldq] / [B*T][ldo], strides in
+ * elements), p / pos_u / pos_v stay fp32; bf16 MFMA, fp32 softmax; T <= 128 keys, dk 64 or 128. */
+int m3_relpos_attention_bf16(const void* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
+                             const int32_t* len, int B, int T, int H, int dk, float scale, void* out, int ldo, m3_stream stream);
 /* Depthwise conv (k odd, pad (k-1)/2) + LayerNorm (gamma NULL = none) + SiLU on channel-last rows;
  * replaces convolution.py:134-152.  w_kc [K][D] = depthwise weight (D,1,K) transposed. */
 int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,

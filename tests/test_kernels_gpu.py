@@ -329,6 +329,33 @@ def test_relpos_attention(B, T, H, dk, lens):
     close(out, want, 3e-5, 3e-5)
 
 
+@pytest.mark.parametrize("B,T,H,dk,lens", [(1, 50, 8, 64, [50]), (2, 36, 8, 64, [36, 20]), (1, 124, 8, 64, [124]), (1, 128, 8, 64, [128]),
+                                           (16, 124, 8, 64, [124, 12, 99, 124, 77, 64, 65, 1, 124, 33, 120, 124, 50, 63, 17, 101]),
+                                           (12, 70, 4, 128, [70, 66, 3, 64, 65, 70, 1, 20, 70, 70, 48, 49]), (3, 17, 4, 128, [17, 16, 15])])
+def test_relpos_attention_bf16(B, T, H, dk, lens):
+    """The attention core on bf16 rows (16-bit modes of long batches): one work-group per (utterance, head), transposed
+    scores on the bf16 MFMA, fp32 softmax.  Reference: fp64 evaluation on the bf16 inputs (q + u, q + v rounded to bf16 as
+    the kernel does; the probabilities' rounding to bf16 before P.V is the kernel's own error: 2^-9 relative)."""
+    D = H * dk
+    qkv, p = rnd(B * T, 3 * D, seed=1).to(torch.bfloat16), rnd(T, D, seed=2)
+    u, v = rnd(H, dk, seed=3, scale=0.3), rnd(H, dk, seed=4, scale=0.3)
+    L = torch.tensor(lens, dtype=torch.int32)
+    out = ops.relpos_attention_bf16(dev(qkv), dev(p), dev(u), dev(v), dev(L), B, T, H, dk)
+    assert out.dtype == torch.bfloat16
+    q, k, vv = [t.float().view(B, T, H, dk) for t in qkv.view(B, T, 3 * D).split(D, -1)]
+    r16 = lambda t: t.to(torch.bfloat16).double()
+    pp = r16(p).view(1, T, H, dk)
+    ac = torch.matmul(r16(q + u).transpose(1, 2), k.double().permute(0, 2, 3, 1))
+    bd = torch.matmul(r16(q + v).transpose(1, 2), pp.permute(0, 2, 3, 1))
+    pad = torch.arange(T).view(1, 1, 1, T) >= L.view(B, 1, 1, 1)
+    att = torch.softmax(((ac + bd) / math.sqrt(dk)).masked_fill(pad, -float("inf")), -1).masked_fill(pad, 0.0)
+    want = torch.matmul(att, vv.double().transpose(1, 2)).transpose(1, 2).reshape(B, T, D)
+    got = out.float().view(B, T, D)
+    valid = torch.arange(T).view(1, -1) < L.view(-1, 1)
+    close(got[valid], want[valid], 1.2e-2, 1.2e-2)          # bf16 probabilities and bf16 output: 2^-8 relative each
+    assert bool(torch.isfinite(out.float()).all())
+
+
 # ------------------------------------------------------------------------------------------ conv pieces
 @pytest.mark.parametrize("B,T,D,K", [(1, 50, 512, 15), (2, 36, 512, 15), (2, 9, 32, 15), (1, 5, 64, 7),
                                      (16, 124, 512, 15), (7, 99, 512, 7), (130, 5, 64, 15)])   # >= 512 rows: 8 frames per workgroup
