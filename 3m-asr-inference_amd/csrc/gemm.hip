@@ -34,7 +34,16 @@
 #include "common.h"
 #include "kernels.h"
 
+// -DM3_GEMM_DIAG: phase stamps (s_memtime) of every work-group of gemm_f32_kernel into a debug buffer (tools/diag_gemm_f32.py)
+#ifdef M3_GEMM_DIAG
+#define M3_GDIAG(...) __VA_ARGS__
+#else
+#define M3_GDIAG(...)
+#endif
+
 namespace m3 {
+
+M3_GDIAG(__device__ unsigned long long g_gemm_dbg[2048 * 8];)
 
 // K-steps per in-flight load group: 2 buffers x G x (NT + MT) float4 must fit the per-lane register
 // budget (512 VGPR+AGPR for 4 waves, 256 for 8, 128 for 16 waves per workgroup) without spilling.
@@ -60,6 +69,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   __shared__ float rsum[LN == LN_EPI ? NW : 1][16 * MT][2];
   __shared__ __attribute__((aligned(16))) float ln_g[LN == LN_PRO ? 1024 : 4], ln_b[LN == LN_PRO ? 1024 : 4];
 
+  M3_GDIAG(unsigned long long dg[8]; dg[0] = __builtin_amdgcn_s_memtime();)
+  // ONE batch of kernel-argument loads.  hipcc fetches each field of the by-value parameter block where it is first used: the
+  // prologue was ~8 dependent rounds of s_load + s_waitcnt (2 400 cycles = 1.1 us before the first global load was issued,
+  // in-kernel stamps, tools/diag_gemm_f32.py).  Naming the fields as scalar operands of one empty asm statement makes it load
+  // them together, one wait.
+  asm volatile("" ::"s"(p.A), "s"(p.lda), "s"(p.W), "s"(p.bias), "s"(p.Y), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.mode),
+               "s"(p.n_tiles), "s"(p.m_tiles), "s"(p.xcd_swizzle), "s"(p.m_dev), "s"(p.resid), "s"(p.ldr), "s"(p.act), "s"(p.alpha),
+               "s"(p.mask_in), "s"(p.mask_out), "s"(p.row_len), "s"(p.rows_per_batch));
+  if (LN == LN_EPI) asm volatile("" ::"s"(p.ln_wsum), "s"(p.ln_wbeta), "s"(p.ln_eps));
+  if (LN == LN_PRO) asm volatile("" ::"s"(p.ln_gamma), "s"(p.ln_beta), "s"(p.ln_eps), "s"(p.ln_out), "s"(p.ld_ln_out), "s"(p.ln_on_a2));
+  if (!CONV) asm volatile("" ::"s"(p.A2), "s"(p.lda2), "s"(p.K1));
+  if (CONV) asm volatile("" ::"s"(p.conv_T1), "s"(p.conv_F1), "s"(p.conv_T2), "s"(p.conv_F2), "s"(p.conv_C));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int Nout = GLU ? (p.N >> 1) : p.N;
@@ -86,11 +107,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   // ---- per-lane row descriptors ----
   const float* arow[MT];
   const float* arow2[MT];
-  bool a_zero[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = min(m0 + 16 * mt + col, p.M - 1);
-    a_zero[mt] = false;
     arow2[mt] = nullptr;
     if (CONV) {
       const int f2 = m % p.conv_F2;
@@ -101,7 +120,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
       arow[mt] = p.A + (size_t)m * p.lda + 4 * kq;
       if (p.mode == GEMM_A_CONCAT2) arow2[mt] = p.A2 + (size_t)m * p.lda2 + 4 * kq;
     }
-    if (p.mask_in) a_zero[mt] = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
   }
   const float* wrow[NT];
 #pragma unroll
@@ -113,6 +131,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr bool DUAL = MT * NT <= 2;
+  f32x4 acc2[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s1[MT], s2[MT];   // LN_EPI: this lane's share of sum(a), sum(a^2) of row (16*mt + col)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) s1[mt] = s2[mt] = 0.f;
@@ -144,6 +168,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
     }
   };
 
+  const int ngroups = (nsteps + NW * G - 1) / (NW * G);
+  M3_GDIAG(dg[1] = __builtin_amdgcn_s_memtime();)
+  // (Compile-time load offsets for the common exact shape -- one base address per row, no per-load address arithmetic -- were
+  //  tried: issue-to-data time unchanged (4 830 vs 4 650 cycles).  The loads are not issue-bound: a CU keeps ~16 KB of misses in
+  //  flight whatever the instruction stream, so 64 KB per work-group take ~4 latencies.)
+  load_group(0, 0);
+  M3_GDIAG(dg[2] = __builtin_amdgcn_s_memtime();)
+  // (everything below is issued behind the first group of operand loads: it is needed at epilogue time only)
   // the epilogue wave's bias / residual are requested up front (they would otherwise be a dependent
   // memory round trip at the very end of a microsecond-scale kernel)
   const int ep_mt = wave;              // wave w finishes row sub-tile w (w < MT)
@@ -171,9 +203,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
       }
     }
   }
+  // padded frames (masked_fill(0) before / after the layer, masked_fill_kernel.cu:27-54): resolved here for the rows this lane
+  // finishes.  An input-masked row has a zero A row, i.e. a zero accumulator: the epilogue writes that instead of zeroing the
+  // A fragments in front of every MFMA (a select + hazard nop per MFMA on the critical path of a one-tile wave)
+  bool pad4[4] = {false, false, false, false};
+  if (is_ep && (p.mask_in || p.mask_out)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(m0 + 16 * ep_mt + 4 * kq + r, p.M - 1);
+      pad4[r] = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+    }
+  }
 
-  const int ngroups = (nsteps + NW * G - 1) / (NW * G);
-  load_group(0, 0);
 
   // ---- LN_PRO: row statistics (two-pass) + gamma/beta to LDS, while the first loads are in flight ----
   float a_mean[MT], a_rstd[MT];
@@ -262,16 +303,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
             s1[mt] += (a[0] + a[1]) + (a[2] + a[3]);
             s2[mt] += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
           }
-          if (a_zero[mt]) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t) {
+            if (DUAL) {       // two independent accumulation chains (k even / odd inside the step): the fp32 MFMA has a 40-cycle
+              //                 dependent latency against a 32-cycle issue, and a one-tile wave has nothing else to interleave
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mt][t] = mfma16(a[j], wbuf[buf][i][t][j], acc[mt][t]);
+              for (int j = 0; j < 4; j += 2) {
+                acc[mt][t] = mfma16(a[j], wbuf[buf][i][t][j], acc[mt][t]);
+                acc2[mt][t] = mfma16(a[j + 1], wbuf[buf][i][t][j + 1], acc2[mt][t]);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[mt][t] = mfma16(a[j], wbuf[buf][i][t][j], acc[mt][t]);
+            }
+          }
         }
       }
     }
   };
 
+  M3_GDIAG(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg[3] = __builtin_amdgcn_s_memtime();)
   if (NBUF == 1) {
     compute_group(0, 0);
   } else {
@@ -285,6 +336,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
     }
   }
 
+  if (DUAL) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mt][t] += acc2[mt][t];
+  }
+  M3_GDIAG(asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); dg[4] = __builtin_amdgcn_s_memtime();)
   // ---- cross-wave K reduction through LDS, then epilogue (wave w finishes row sub-tile w) ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -307,6 +365,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
     }
   }
   __syncthreads();
+  M3_GDIAG(dg[5] = __builtin_amdgcn_s_memtime();)
 
   if (is_ep) {
     const int mt = ep_mt;
@@ -329,8 +388,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
         const int m = m0 + row;
         if (m >= p.M) continue;
         float y0 = v[0][r], y1 = v[NT - 1][r];
-        bool pad = false;
-        if (p.mask_in || p.mask_out) pad = (m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch];
+        const bool pad = pad4[r];
+        if (LN != LN_EPI && p.mask_in && pad) y0 = y1 = 0.f;      // zero A row -> zero accumulator
         if (LN == LN_EPI) {
           float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -360,6 +419,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
       }
     }
   }
+  M3_GDIAG(dg[6] = __builtin_amdgcn_s_memtime();
+           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+           dg[7] = __builtin_amdgcn_s_memtime();
+           if (lane == 0 && wave == 0 && blockIdx.x < 2048) {
+             unsigned long long* o = g_gemm_dbg + (size_t)blockIdx.x * 8;
+             for (int i = 0; i < 8; ++i) o[i] = dg[i];
+             // where the work-group ran: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), packed above the last stamp's low 40 bits
+             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+             o[7] = (dg[7] & 0xffffffffffull) | ((unsigned long long)(hw & 0xffff) << 40) | ((unsigned long long)(xcc & 0xf) << 56);
+           })
 }
 
 int launch_gemm_f32_tiled(const GemmParams& p, hipStream_t stream);   // gemm_f32_tiled.hip
@@ -465,3 +534,9 @@ int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {
 }
 
 }  // namespace m3
+
+#ifdef M3_GEMM_DIAG
+extern "C" int m3_debug_gemm_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(m3::g_gemm_dbg), bytes < sizeof(m3::g_gemm_dbg) ? bytes : sizeof(m3::g_gemm_dbg));
+}
+#endif
