@@ -224,8 +224,16 @@ int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, cons
                                  (hipStream_t)stream);
 }
 int m3_relpos_attention_bf16(const void* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
-                             const int32_t* len, int B, int T, int H, int dk, float scale, void* out, int ldo, m3_stream stream) {
-  return launch_relpos_attention_bf16(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo, (hipStream_t)stream);
+                             const int32_t* len, int B, int T, int H, int dk, float scale, int chunk, int left_chunks,
+                             void* out, int ldo, m3_stream stream) {
+  return launch_relpos_attention_bf16(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo, (hipStream_t)stream,
+                                      nullptr, chunk, left_chunks);
+}
+int m3_relpos_attention_chunk(const float* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
+                              const int32_t* len, int B, int T, int H, int dk, float scale, int chunk, int left_chunks,
+                              float* out, int ldo, m3_stream stream) {
+  return launch_relpos_attention(qkv, ldq, p, ldp, pos_u, pos_v, len, B, T, H, dk, scale, out, ldo, (hipStream_t)stream, 0,
+                                 nullptr, chunk, left_chunks);
 }
 int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
                       float eps, int B, int T, int D, int K, float* out, m3_stream stream) {

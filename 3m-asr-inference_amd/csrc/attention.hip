@@ -26,8 +26,12 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
                                                               const float* __restrict__ pos_v,
                                                               const int32_t* __restrict__ row_len, int T, int D,
                                                               float scale, float* __restrict__ out, int ldo, int out_bf16,
-                                                              const int32_t* __restrict__ row0, int QT, int H, int xcd_map) {
+                                                              const int32_t* __restrict__ row0, int QT, int H, int xcd_map,
+                                                              int chunk, int left_chunks) {
   constexpr int KS = DK / 16;
+  // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~5 dependent s_load rounds otherwise)
+  asm volatile("" ::"s"(qkv), "s"(ldq), "s"(pmat), "s"(ldp), "s"(pos_u), "s"(pos_v), "s"(row_len), "s"(T), "s"(D), "s"(scale),
+               "s"(out), "s"(ldo), "s"(out_bf16), "s"(row0), "s"(QT), "s"(H), "s"(xcd_map), "s"(chunk), "s"(left_chunks));
   __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
   __shared__ float mo[4][16][DK + 1];   // per-wave partial O
   __shared__ float mm[4][16], ml[4][16];
@@ -80,6 +84,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     l_run[r] = 0.f;
   }
 
+  // static chunk mask (utils/mask.py:42-75 subsequent_chunk_mask, :127-134 static_chunk_size): query i sees keys
+  // [max((i / chunk - left_chunks) chunk, 0), min((i / chunk + 1) chunk, T)) -- all left chunks when left_chunks < 0 --
+  // besides the padding mask key < len.  chunk <= 0: full context.  Rows of this lane's accumulators: 4 kq + r.
+  int klo[4], khi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qrow = q0 + 4 * kq + r;
+    klo[r] = 0;
+    khi[r] = len;
+    if (chunk > 0) {
+      const int c = qrow / chunk;
+      klo[r] = left_chunks < 0 ? 0 : max((c - left_chunks) * chunk, 0);
+      khi[r] = min(min((c + 1) * chunk, T), len);
+    }
+  }
   for (int j0 = 16 * wave; j0 < len; j0 += 64) {
     const int kj = min(j0 + col, last);
     const float* krow = qkv + (brow + kj) * ldq + D + h * DK + 4 * kq;
@@ -107,13 +126,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
         sc = mfma16(qu[s][j], kb[s][j], sc);
         sc = mfma16(qv[s][j], pb[s][j], sc);
       }
-    const bool valid = (j0 + col) < len;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const bool valid = (j0 + col) >= klo[r] && (j0 + col) < khi[r];
       const float sv = valid ? sc[r] * scale : -INFINITY;
       const float m_new = fmaxf(m_run[r], group16_max(sv));
       const float pexp = valid ? expf(sv - m_new) : 0.f;
-      const float corr = expf(m_run[r] - m_new);
+      const float corr = (m_new == -INFINITY) ? 1.f : expf(m_run[r] - m_new);   // (a key tile wholly outside the row's chunk window)
       l_run[r] = l_run[r] * corr + group16_sum(pexp);
       m_run[r] = m_new;
 #pragma unroll
@@ -152,18 +171,19 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     float l_tot = 0.f, acc = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float f = expf(mm[w][i] - m_tot);   // waves without a key tile hold m = -inf -> factor 0
+      const float f = (mm[w][i] == -INFINITY) ? 0.f : expf(mm[w][i] - m_tot);   // waves without a (visible) key tile: factor 0
       l_tot += ml[w][i] * f;
       acc += mo[w][i][d] * f;
     }
-    if (out_bf16) reinterpret_cast<bf16_t*>(out)[(brow + qrow) * ldo + h * DK + d] = (bf16_t)(acc / l_tot);
-    else out[(brow + qrow) * ldo + h * DK + d] = acc / l_tot;
+    const float o = l_tot > 0.f ? acc / l_tot : 0.f;       // a row with no visible key (padded query under a chunk mask): zeros
+    if (out_bf16) reinterpret_cast<bf16_t*>(out)[(brow + qrow) * ldo + h * DK + d] = (bf16_t)o;
+    else out[(brow + qrow) * ldo + h * DK + d] = o;
   }
 }
 
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream, int out_bf16, const int32_t* row0) {
+                            float* out, int ldo, hipStream_t stream, int out_bf16, const int32_t* row0, int chunk, int left_chunks) {
   M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
   M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0, "attention: row strides must be multiples of 4");
   const int QT = cdiv(T, 16);
@@ -172,7 +192,7 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
   const int xcd_map = ((H * B) % 8 == 0) ? 1 : 0;
 #define M3_ATT_CASE(DK_)                                                                                   \
   hipLaunchKernelGGL((relpos_attention_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, pmat, ldp, pos_u, \
-                     pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0, QT, H, xcd_map)
+                     pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0, QT, H, xcd_map, chunk, left_chunks)
   switch (dk) {
     case 16: M3_ATT_CASE(16); break;
     case 32: M3_ATT_CASE(32); break;
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t
                                                                    const float* __restrict__ pos_v,
                                                                    const int32_t* __restrict__ row_len, int T, int D, int H,
                                                                    float scale, bf16_t* __restrict__ out, int ldo,
-                                                                   const int32_t* __restrict__ row0) {
+                                                                   const int32_t* __restrict__ row0, int chunk, int left_chunks) {
   constexpr int KLD = DK + 8;                                  // bf16 elements per K / P row in LDS (conflict-free 16-B fragment reads)
   constexpr int VLD = kAttTP + 8;                              // bf16 elements per Vt row (one channel, all keys)
   constexpr int KS = DK / 32;                                  // 32-deep k-steps of the score products
@@ -295,6 +315,13 @@ __global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t
         qv[s][4 + j] = (bf16_t)((float)q8[i][s][4 + j] + pv[s][1][j]);
       }
     }
+    // static chunk mask (see the fp32 kernel): this lane's query sees keys [klo, khi)
+    int klo = 0, khi = len;
+    if (chunk > 0) {
+      const int c = (q0 + col) / chunk;
+      klo = left_chunks < 0 ? 0 : max((c - left_chunks) * chunk, 0);
+      khi = min(min((c + 1) * chunk, T), len);
+    }
     // scores, transposed: sT[t][r] = s(query col, key 16 t + 4 kq + r)
     f32x4 sT[kAttTP / 16];
     float mx = -INFINITY;
@@ -312,7 +339,8 @@ __global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool valid = (16 * t + 4 * kq + r) < len;
+        const int key = 16 * t + 4 * kq + r;
+        const bool valid = key >= klo && key < khi;
         sT[t][r] = valid ? sT[t][r] * scale : -INFINITY;
         mx = fmaxf(mx, sT[t][r]);
       }
@@ -320,16 +348,17 @@ __global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                    // the four key quarters of this query's column
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
+    const float mref = mx == -INFINITY ? 0.f : mx;            // (no visible key at all: a padded query under a chunk mask)
 #pragma unroll
     for (int t = 0; t < kAttTP / 16; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sT[t][r] = __expf(sT[t][r] - mx);                      // masked keys: exp(-inf) = 0 (len >= 1: mx is finite)
+        sT[t][r] = __expf(sT[t][r] - mref);                    // masked keys: exp(-inf) = 0
         sum += sT[t][r];
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
     // O^T = V^T P^T over pairs of key tiles
     f32x4 oT[NCH];
 #pragma unroll
@@ -385,7 +414,7 @@ int init_relpos_attention_bf16_kernels() {
 
 int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, int ldp, const float* pos_u, const float* pos_v,
                                  const int32_t* row_len, int B, int T, int H, int dk, float scale, void* out, int ldo,
-                                 hipStream_t stream, const int32_t* row0) {
+                                 hipStream_t stream, const int32_t* row0, int chunk, int left_chunks) {
   M3_REQUIRE(B > 0 && T > 0 && H > 0, "attention: empty problem");
   M3_REQUIRE(relpos_attention_bf16_supports(T, dk), "attention (bf16 rows): T'=%d > %d keys or d_k=%d not 64 / 128", T, kAttTP, dk);
   M3_REQUIRE((ldq & 7) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, "attention (bf16 rows): row strides must be multiples of 8 / 4 / 4");
@@ -393,10 +422,10 @@ int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, in
   const int D = H * dk;
   if (dk == 64)
     hipLaunchKernelGGL((relpos_attention_bf16_kernel<64>), dim3(B * H), dim3(256), att16_lds_bytes<64>(), stream, (const bf16_t*)qkv,
-                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0);
+                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0, chunk, left_chunks);
   else
     hipLaunchKernelGGL((relpos_attention_bf16_kernel<128>), dim3(B * H), dim3(256), att16_lds_bytes<128>(), stream, (const bf16_t*)qkv,
-                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0);
+                       ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, H, scale, (bf16_t*)out, ldo, row0, chunk, left_chunks);
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -27,6 +27,9 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
                                                               const int32_t* __restrict__ row0,
                                                               const int32_t* __restrict__ row_len) {
   __shared__ float red[2][16];
+  // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~6 dependent s_load rounds otherwise)
+  asm volatile("" ::"s"(z), "s"(w_kc), "s"(bias), "s"(gamma), "s"(beta), "s"(eps), "s"(T), "s"(D), "s"(K), "s"(out), "s"(out_bf16),
+               "s"(pad_of), "s"(row0), "s"(row_len));
   const int row = blockIdx.x;
   // padded rows: row = b T + t.  Packed rows (pad_of != null): row p is frame pad_of[p] = b T + t of the padded layout
   // (-1 past the last packed row P); utterance b owns rows [row0[b], row0[b] + len).  The reference runs the conv on the

@@ -528,9 +528,10 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* pu = w.pos_u; const float* pv = w.pos_v;
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
+    const int chunk = c.static_chunk_size, left_chunks = c.num_left_chunks;   // static chunk mask (0 = full context)
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
-      if (att16) return launch_relpos_attention_bf16(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, row0);
-      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0);
+      if (att16) return launch_relpos_attention_bf16(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, row0, chunk, left_chunks);
+      return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0, chunk, left_chunks);
     }, stage_info(att16 ? "relpos_attention_bf16_kernel" : "relpos_attention_kernel", 1,
                   (double)S * D * (att16 ? 8 : (12 + (a16 ? 2 : 4))) + (double)Tp * D * 4, 6.0 * Tp * D * S));
     GemmParams o;

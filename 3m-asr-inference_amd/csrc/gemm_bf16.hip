@@ -57,6 +57,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16w_kernel(const GemmParams p)
   __shared__ float red[NW][MT * NT][256];
   __shared__ float rsum[LN ? NW : 1][16 * MT][2];
 
+  // one batch of kernel-argument loads (gemm.hip: the lazily loaded parameter block cost ~8 dependent s_load rounds)
+  asm volatile("" ::"s"(p.A), "s"(p.lda), "s"(p.W), "s"(p.bias), "s"(p.Y), "s"(p.ldy), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.mode),
+               "s"(p.n_tiles), "s"(p.m_tiles), "s"(p.xcd_swizzle), "s"(p.m_dev), "s"(p.resid), "s"(p.ldr), "s"(p.act), "s"(p.alpha),
+               "s"(p.mask_in), "s"(p.mask_out), "s"(p.row_len), "s"(p.rows_per_batch));
+  if (LN) asm volatile("" ::"s"(p.ln_wsum), "s"(p.ln_wbeta), "s"(p.ln_eps));
+  if (CONV) asm volatile("" ::"s"(p.conv_T1), "s"(p.conv_F1), "s"(p.conv_T2), "s"(p.conv_F2), "s"(p.conv_C));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int Nout = GLU ? (p.N >> 1) : p.N;

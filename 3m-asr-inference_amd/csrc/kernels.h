@@ -185,14 +185,15 @@ int launch_bmm(const float* a, const float* b, float* c, int batch, int M, int N
 // ---- fused rel-pos attention (attention.hip) ----
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
-                            float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr);
+                            float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr,
+                            int chunk = 0, int left_chunks = -1);   // chunk > 0: static chunk mask (utils/mask.py:42-75)
 
 // the same on bf16 rows (16-bit modes, T' <= 128): qkv bf16 [B*T][ldq], out bf16; one work-group per (utterance, head)
 bool relpos_attention_bf16_supports(int T, int dk);
 int init_relpos_attention_bf16_kernels();
 int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, int ldp, const float* pos_u, const float* pos_v,
                                  const int32_t* row_len, int B, int T, int H, int dk, float scale, void* out, int ldo,
-                                 hipStream_t stream, const int32_t* row0 = nullptr);
+                                 hipStream_t stream, const int32_t* row0 = nullptr, int chunk = 0, int left_chunks = -1);
 
 // ---- conv module / subsampling (conv.hip) ----
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,

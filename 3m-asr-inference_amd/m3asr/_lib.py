@@ -46,7 +46,7 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
         "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
-        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages", "fork_embed")]
+        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages", "fork_embed", "static_chunk_size", "num_left_chunks")]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
@@ -110,7 +110,8 @@ SIGNATURES = {
     "m3_conv2d_3x3s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m3_layer_norm": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_relpos_attention": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
-    "m3_relpos_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "m3_relpos_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp]),
+    "m3_relpos_attention_chunk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _i, _vp]),
     "m3_dwconv_ln_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     "m3_subsample_conv1": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "m3_subsample_conv1_cmvn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -42,6 +42,11 @@ class EncoderConfig:
     # plan (m3asr/calibrate.py) -- the reference's --int8 slot (builder.py:39-49, builder_helper.py:109-123)
     fp8_activations: bool = False
     log_softmax_out: bool = False  # output log_softmax(logits) (+ output_bias) instead of raw logits (builder.py:77-88)
+    # static chunk mask of the streaming encoders (model/conformer.py:40,142-175 -> utils/mask.py:127-134): with
+    # static_chunk_size > 0 every attention (embed and main encoder) sees, for query frame i, the keys of its own chunk and
+    # of num_decoding_left_chunks chunks to the left (< 0: all of them) -- besides the padding mask.  0 = full context.
+    static_chunk_size: int = 0
+    num_decoding_left_chunks: int = -1
 
     def fp8_label(self):
         """What the fp8 mode of this config computes in (for reports: a weight-only mode must not read as fp8 MFMA)."""

@@ -40,6 +40,8 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.fp8_activations = int(bool(getattr(cfg, "fp8_activations", False)) and cfg.weight_dtype == "fp8")
     ec.ep_stages = int(bool(ep_stages))
     ec.fork_embed = 0 if fork_embed is None else (1 if fork_embed else -1)
+    ec.static_chunk_size = int(getattr(cfg, "static_chunk_size", 0))
+    ec.num_left_chunks = int(getattr(cfg, "num_decoding_left_chunks", -1))
     return ec
 
 

@@ -239,24 +239,31 @@ def layer_norm(x, gamma, beta, eps):
     return y
 
 
-def relpos_attention(qkv, p, pos_u, pos_v, lens, B, T, H, dk):
+def relpos_attention(qkv, p, pos_u, pos_v, lens, B, T, H, dk, chunk=0, left_chunks=-1):
+    """chunk > 0: static chunk mask (utils/mask.py:42-75): query i sees keys of its chunk and of `left_chunks` chunks to the
+    left (< 0: all) -- besides the padding mask."""
     lib = _lib.load()
     D = H * dk
     out = torch.empty(B * T, D, dtype=torch.float32, device=qkv.device)
+    if chunk > 0:
+        check(lib.m3_relpos_attention_chunk(_f32(qkv), qkv.stride(0), _f32(p), p.stride(0), _f32(pos_u), _f32(pos_v), _i32(lens),
+                                            B, T, H, dk, 1.0 / math.sqrt(dk), int(chunk), int(left_chunks), _p(out), D, _stream()),
+              "m3_relpos_attention_chunk")
+        return out
     check(lib.m3_relpos_attention(_f32(qkv), qkv.stride(0), _f32(p), p.stride(0), _f32(pos_u), _f32(pos_v),
                                   _i32(lens), B, T, H, dk, 1.0 / math.sqrt(dk), _p(out), D, _stream()),
           "m3_relpos_attention")
     return out
 
 
-def relpos_attention_bf16(qkv, p, pos_u, pos_v, lens, B, T, H, dk):
+def relpos_attention_bf16(qkv, p, pos_u, pos_v, lens, B, T, H, dk, chunk=0, left_chunks=-1):
     """the same on bf16 rows: qkv (B*T, 3*H*dk) bf16 -> ctx (B*T, H*dk) bf16 (T <= 128)"""
     lib = _lib.load()
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     D = H * dk
     out = torch.empty(B * T, D, dtype=torch.bfloat16, device=qkv.device)
     check(lib.m3_relpos_attention_bf16(_p(qkv), 3 * D, _f32(p), p.stride(0), _f32(pos_u), _f32(pos_v), _i32(lens), B, T, H, dk,
-                                       1.0 / math.sqrt(dk), _p(out), D, _stream()), "m3_relpos_attention_bf16")
+                                       1.0 / math.sqrt(dk), int(chunk), int(left_chunks), _p(out), D, _stream()), "m3_relpos_attention_bf16")
     return out
 
 

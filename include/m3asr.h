@@ -240,7 +240,14 @@ int m3_relpos_attention(const float* qkv, int ldq, const float* p, int ldp, cons
 /* The same operator on bf16 rows (16-bit modes of long batches): qkv and out are bf16 ([B*T][ldq] / [B*T][ldo], strides in
  * elements), p / pos_u / pos_v stay fp32; bf16 MFMA, fp32 softmax; T <= 128 keys, dk 64 or 128. */
 int m3_relpos_attention_bf16(const void* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
-                             const int32_t* len, int B, int T, int H, int dk, float scale, void* out, int ldo, m3_stream stream);
+                             const int32_t* len, int B, int T, int H, int dk, float scale, int chunk, int left_chunks,
+                             void* out, int ldo, m3_stream stream);
+/* The fp32 core with the static chunk mask of the streaming encoders (utils/mask.py:42-75,127-134): chunk > 0: query i
+ * sees keys [max((i / chunk - left_chunks) chunk, 0), min((i / chunk + 1) chunk, T)) (all left chunks when left_chunks < 0)
+ * and < len[b]; rows with no visible key give zeros.  chunk <= 0: identical to m3_relpos_attention. */
+int m3_relpos_attention_chunk(const float* qkv, int ldq, const float* p, int ldp, const float* pos_u, const float* pos_v,
+                              const int32_t* len, int B, int T, int H, int dk, float scale, int chunk, int left_chunks,
+                              float* out, int ldo, m3_stream stream);
 /* Depthwise conv (k odd, pad (k-1)/2) + LayerNorm (gamma NULL = none) + SiLU on channel-last rows;
  * replaces convolution.py:134-152.  w_kc [K][D] = depthwise weight (D,1,K) transposed. */
 int m3_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
@@ -376,6 +383,10 @@ typedef struct m3_engine_config {
                                   * its own scratch buffers.  1 = on, 0 / -1 = off (default: with several execution contexts the
                                   * extra branch costs more queue concurrency than it saves latency).  Stage-wise
                                   * runs (m3_engine_run) stay one chain; results are identical either way */
+  int32_t static_chunk_size;     /* > 0: static chunk mask in every attention (add_optional_chunk_mask, utils/mask.py:127-134;
+                                  * subsequent_chunk_mask :42-75): query frame i sees keys [max((i / c - left) c, 0),
+                                  * min((i / c + 1) c, T')) and < len.  0 = full context */
+  int32_t num_left_chunks;       /* chunks to the left a query sees with static_chunk_size > 0; < 0: all */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {

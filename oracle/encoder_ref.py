@@ -95,11 +95,25 @@ def ffn(x, w, p):
     return F.linear(h, w[p + "w_2.weight"], w[p + "w_2.bias"])
 
 
-def rel_pos_mha(x, pos_emb, lens, w, p, h):
+def chunk_mask(size, chunk_size, num_left_chunks=-1):
+    """subsequent_chunk_mask (utils/mask.py:42-75), restated: query i sees keys
+    [max((i // chunk - left) * chunk, 0), min((i // chunk + 1) * chunk, size)); all left chunks when left < 0.
+    Pinned by tests/golden/chunk_mask.npz (generated from the reference's own function, oracle/gen_golden_chunk.py)."""
+    i = torch.arange(size).view(-1, 1)
+    j = torch.arange(size).view(1, -1)
+    c = i // chunk_size
+    start = torch.zeros_like(c) if num_left_chunks < 0 else torch.clamp((c - num_left_chunks) * chunk_size, min=0)
+    ending = torch.clamp((c + 1) * chunk_size, max=size)
+    return (j >= start) & (j < ending)
+
+
+def rel_pos_mha(x, pos_emb, lens, w, p, h, static_chunk_size=0, num_left_chunks=-1):
     """RelPositionMultiHeadedAttention.forward (layer/attention.py:320-384) +
     forward_attention_trt (:199-239) + AttMaskedSoftmax (common.cuh:264-360):
     scores = ((q+u)k^T + (q+v)p^T) / sqrt(dk)  -- NO rel_shift; softmax over keys j < len[b],
-    padded keys get probability 0."""
+    padded keys get probability 0.  static_chunk_size > 0: additionally the static chunk mask of
+    add_optional_chunk_mask (utils/mask.py:127-134): masks & subsequent_chunk_mask(T, chunk, left); a query row with no
+    visible key (a padded frame) gets zeros."""
     B, T, D = x.shape
     dk = D // h
     q = F.linear(x, w[p + "linear_q.weight"], w[p + "linear_q.bias"]).view(B, T, h, dk)
@@ -112,7 +126,10 @@ def rel_pos_mha(x, pos_emb, lens, w, p, h):
     bd = torch.matmul(q_v, pp.permute(0, 2, 3, 1))
     scores = (ac + bd) * (1.0 / math.sqrt(dk))
     key_pad = torch.arange(T).view(1, 1, 1, T) >= lens.view(B, 1, 1, 1)
+    if static_chunk_size > 0:
+        key_pad = key_pad | ~chunk_mask(T, static_chunk_size, num_left_chunks).view(1, 1, T, T)
     attn = torch.softmax(scores.masked_fill(key_pad, -float("inf")), dim=-1).masked_fill(key_pad, 0.0)
+    attn = torch.nan_to_num(attn, nan=0.0)              # rows with no visible key
     ctx = torch.matmul(attn, v.transpose(1, 2))
     ctx = ctx.transpose(1, 2).contiguous().view(B, T, D)
     return F.linear(ctx, w[p + "linear_out.weight"], w[p + "linear_out.bias"])
@@ -236,7 +253,8 @@ def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe
     x = x + 0.5 * ffn(layer_norm(x, w, p + "norm_ff_macaron.", eps), w, p + "feed_forward_macaron.")
     if taps is not None:
         taps[tag + "after_macaron"] = x
-    x = x + rel_pos_mha(layer_norm(x, w, p + "norm_mha.", eps), pos_emb, lens, w, p + "self_attn.", heads)
+    x = x + rel_pos_mha(layer_norm(x, w, p + "norm_mha.", eps), pos_emb, lens, w, p + "self_attn.", heads,
+                        getattr(cfg, "static_chunk_size", 0), getattr(cfg, "num_decoding_left_chunks", -1))
     if taps is not None:
         taps[tag + "after_mha"] = x
     x = x + conv_module(layer_norm(x, w, p + "norm_conv.", eps), lens, w, p + "conv_module.", kernel, norm)

