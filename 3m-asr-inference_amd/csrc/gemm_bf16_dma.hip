@@ -64,6 +64,7 @@ template <bool GLU, bool LN, int STAGES>
 __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dma_lds[];
   __shared__ float stats[DBM][2];
+  __shared__ float stat_out[DBM][2];
   __shared__ int rowpad[DBM];
   constexpr int MT = 4, NT = 4;
   M3_DIAG(unsigned long long dg[8]; dg[0] = __builtin_amdgcn_s_memtime();)
@@ -221,20 +222,20 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel
   __syncthreads();
   M3_DIAG(dg[4] = __builtin_amdgcn_s_memtime();)
 
-  // one row of the sweep; rv = the residual values of this lane's 4 columns
-  auto sweep_row = [&](int it, const f32x4& rv, bool vec) {
+  // one row of the sweep; rv = the residual values of this lane's 4 columns, (v0, v1, pad, mean, rstd) = what the LDS image and
+  // the row tables hold for it.  In the fast path these were all read AHEAD of the sweep: with the ds_read inside, every
+  // iteration was the serial chain ds_read -> wait -> arithmetic -> store (~600 cycles per iteration and wave in the stamps, 9.7 k
+  // cycles per tile: twice the k-loop's MFMA time); read up front the sweep is arithmetic and stores only.
+  // Stores are ISSUE-bound here, not byte-bound (MI355X_MICROARCH.md, store tail: a CU retires a store wave-instruction every
+  // ~50-70 cycles whatever its width -- the stamps showed 9 k cycles for the 192 instructions of a tile with fp32 + bf16 + stats
+  // outputs).  So the sweep issues as few as the bytes allow: fp32 rows as dwordx4 (64 per tile); the bf16 rows as dwordx4 too --
+  // a lane holds 4 columns = 8 bytes, so lanes 2i / 2i+1 trade halves over TWO row iterations (even lane: 8 columns of row
+  // `it`, odd lane: 8 columns of row `it + 1`; 32 per tile instead of 64); the row statistics go to LDS and leave as two
+  // instructions per tile after the sweep instead of one per row.
+  auto sweep_row = [&](int it, const f32x4& rv, bool vec, const f32x4& v0, const f32x4& v1, bool pad, float mean, float rstd) -> bf16x4 {
     const int row = (4 * it + wave) * RPI + lane / LPR;
     const int m = m0 + row;
     const bool live = m < p.M && n < Nout;
-    const bool pad = rowpad[row] != 0;
-    float mean = 0.f, rstd = 1.f;
-    if (LN) {
-      mean = stats[row][0];
-      rstd = stats[row][1];
-    }
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + c4);
-    f32x4 v1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + DBN / 2 + c4);
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -280,28 +281,79 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel
         t1 += __shfl_xor(t1, 16, 64);
         t2 += __shfl_xor(t2, 16, 64);
       }
-      if (live && (lane % LPR) == 0) {
-        float* d = p.Yb_stats + ((size_t)m * p.n_tiles + n_tile) * 2;
-        d[0] = t1;
-        d[1] = t2;
+      if ((lane % LPR) == 0) {
+        stat_out[row][0] = t1;
+        stat_out[row][1] = t2;
       }
     }
-    if (live) {
+    if (live && !p.y_bf16) {
       if (vec) {
-        if (p.Yb != nullptr)                        // bf16 copy for the next GEMM's A operand (besides the fp32 output)
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Yb) + (size_t)m * p.ldyb + n) = h;
-        if (p.y_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
-        else stg4(p.Y + (size_t)m * p.ldy + n, y);
+        stg4(p.Y + (size_t)m * p.ldy + n, y);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n + e < Nout) p.Y[(size_t)m * p.ldy + n + e] = y[e];
       }
     }
+    return h;
+  };
+  // bf16 rows of iterations `it` (ha) and `it + 1` (hb): see above.  wide = the tile's column count and the row pitches allow
+  // 16-byte pieces (N a multiple of 8: every shape of the model); else 8 bytes per lane and row as before.
+  const bool wide = ((Nout & 7) == 0) && ((p.ldyb & 7) == 0) && (!p.y_bf16 || (p.ldy & 7) == 0);
+  auto store_bf16_pair = [&](int it, const bf16x4& ha, const bf16x4& hb) {
+    if (p.Yb == nullptr && !p.y_bf16) return;
+    const int row_a = (4 * it + wave) * RPI + lane / LPR, row_b = (4 * (it + 1) + wave) * RPI + lane / LPR;
+    bf16_t* yb = reinterpret_cast<bf16_t*>(p.Yb);
+    bf16_t* y16 = reinterpret_cast<bf16_t*>(p.Y);
+    if (wide) {
+      const bool odd = (lane & 1) != 0;
+      const f32x2 fa = __builtin_bit_cast(f32x2, ha), fb = __builtin_bit_cast(f32x2, hb);
+      const f32x2 give = odd ? fa : fb;
+      const f32x2 recv = f32x2{dpp_mov<0xB1>(give[0]), dpp_mov<0xB1>(give[1])};      // from the neighbour lane (quad_perm [1,0,3,2])
+      const f32x4 out = odd ? f32x4{recv[0], recv[1], fb[0], fb[1]} : f32x4{fa[0], fa[1], recv[0], recv[1]};
+      const int m = m0 + (odd ? row_b : row_a), nn = odd ? n - 4 : n;
+      if (m < p.M && nn < Nout) {
+        if (yb != nullptr) *reinterpret_cast<f32x4*>(yb + (size_t)m * p.ldyb + nn) = out;
+        if (p.y_bf16) *reinterpret_cast<f32x4*>(y16 + (size_t)m * p.ldy + nn) = out;
+      }
+    } else {
+      if (n < Nout) {
+        if (m0 + row_a < p.M) {
+          if (yb != nullptr) *reinterpret_cast<bf16x4*>(yb + (size_t)(m0 + row_a) * p.ldyb + n) = ha;
+          if (p.y_bf16) *reinterpret_cast<bf16x4*>(y16 + (size_t)(m0 + row_a) * p.ldy + n) = ha;
+        }
+        if (m0 + row_b < p.M) {
+          if (yb != nullptr) *reinterpret_cast<bf16x4*>(yb + (size_t)(m0 + row_b) * p.ldyb + n) = hb;
+          if (p.y_bf16) *reinterpret_cast<bf16x4*>(y16 + (size_t)(m0 + row_b) * p.ldy + n) = hb;
+        }
+      }
+    }
+  };
+  auto gather = [&](int it, f32x4& v0, f32x4& v1, bool& pad, float& mean, float& rstd) {
+    const int row = (4 * it + wave) * RPI + lane / LPR;
+    pad = rowpad[row] != 0;
+    mean = 0.f;
+    rstd = 1.f;
+    if (LN) {
+      mean = stats[row][0];
+      rstd = stats[row][1];
+    }
+    v0 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + c4);
+    v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (GLU) v1 = *reinterpret_cast<const f32x4*>(Cs + row * kCLd + DBN / 2 + c4);
   };
   if (fast) {
+    f32x4 v0s[IT], v1s[IT];
+    float means[IT], rstds[IT];
+    bool pads[IT];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) sweep_row(it, res[it], true);
+    for (int it = 0; it < IT; ++it) gather(it, v0s[it], v1s[it], pads[it], means[it], rstds[it]);
+#pragma unroll
+    for (int it = 0; it < IT; it += 2) {
+      const bf16x4 ha = sweep_row(it, res[it], true, v0s[it], v1s[it], pads[it], means[it], rstds[it]);
+      const bf16x4 hb = sweep_row(it + 1, res[it + 1], true, v0s[it + 1], v1s[it + 1], pads[it + 1], means[it + 1], rstds[it + 1]);
+      store_bf16_pair(it, ha, hb);
+    }
   } else {
     for (int it = 0; it < IT; ++it) {               // fp32 output only (the launcher rejects bf16 outputs with N % 4 != 0)
       f32x4 rv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -309,8 +361,17 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel
       if (p.resid)
 #pragma unroll
         for (int e = 0; e < 4; ++e) rv[e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
-      sweep_row(it, rv, false);
+      f32x4 v0, v1;
+      float mean, rstd;
+      bool pad;
+      gather(it, v0, v1, pad, mean, rstd);
+      sweep_row(it, rv, false, v0, v1, pad, mean, rstd);
     }
+  }
+  if (p.Yb_stats != nullptr) {                      // the tile's row statistics: 8 bytes per row, two wave-instructions
+    __syncthreads();
+    if (tid < DBM && m0 + tid < p.M)
+      *reinterpret_cast<f32x2*>(p.Yb_stats + ((size_t)(m0 + tid) * p.n_tiles + n_tile) * 2) = f32x2{stat_out[tid][0], stat_out[tid][1]};
   }
   M3_DIAG(dg[5] = __builtin_amdgcn_s_memtime();
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

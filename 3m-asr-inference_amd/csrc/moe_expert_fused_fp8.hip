@@ -717,19 +717,6 @@ static int fused8_min_rows() {   // read once: the engine freezes the form (and 
   }();
   return v;
 }
-int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F) {
-  const int tiles = cdiv(S, kTok) + E / 2;
-  int fs = 1;
-  if (F % 512 == 0 && tiles < 112) fs = 4;
-  else if (tiles < 224 && F % 256 == 0) fs = 2;
-  while (F / fs > 1024 && fs < 4) fs *= 2;                   // b1 / s1 of a work item's F range: 1024 floats each in LDS
-  return fs;
-}
-bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F) {
-  if (!(D == kD && F % 128 == 0 && F <= 4096 && S >= fused8_min_rows() && S >= 64 * E && E <= 1024)) return false;
-  const int fs = expert_ffn_fused_fp8_fsplit(S, E, D, F);
-  return F % (128 * fs) == 0 && F / fs <= 1024;
-}
 // persistent grid: one work-group per CU, a multiple of 8 (XCDs)
 static int fused8_grid() {
   static int g = 0;
@@ -739,6 +726,31 @@ static int fused8_grid() {
     g = cus >= 8 ? cus / 8 * 8 : 8;
   }
   return g;
+}
+int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F) {
+  static const int forced = [] { const char* e = getenv("M3_FUSED8_FSPLIT"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  // F parts per token tile.  A work item streams its part of the expert's weights (D F / fs bytes of W1 and of W2) plus the
+  // tile's X and Y (128 tokens x D x 4 B each, whatever fs), all at the ~20 B/cycle one CU pulls; the persistent grid is one
+  // work-group per CU, so a launch costs rounds = ceil(tiles fs / CUs) items.  Measured at configs[4]'s share (4480 live rows,
+  // 64 experts, ~70 tiles): fs = 4 -> 54.7 us (2 rounds), fs = 2 -> 40.2 us (1 round), fs = 1 -> 59.9 us -- the model's
+  // 1536 : 1024 : 1536.  (tiles: every expert may end in a partly filled tile.)
+  const int tiles = cdiv(S, kTok) + E / 2;
+  const int cus = fused8_grid();
+  int fs = 1;
+  long best = -1;
+  for (int f = 1; f <= 4; f *= 2) {
+    if (F % (128 * f) != 0) continue;
+    const long cost = (long)cdiv(tiles * f, cus) * (2L * D * F / f + 2L * kTok * D * 4);
+    if (best < 0 || cost < best) { best = cost; fs = f; }
+  }
+  while (F / fs > 1024 && fs < 4) fs *= 2;                   // b1 / s1 of a work item's F range: 1024 floats each in LDS
+  return fs;
+}
+bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F) {
+  if (!(D == kD && F % 128 == 0 && F <= 4096 && S >= fused8_min_rows() && S >= 64 * E && E <= 1024)) return false;
+  const int fs = expert_ffn_fused_fp8_fsplit(S, E, D, F);
+  return F % (128 * fs) == 0 && F / fs <= 1024;
 }
 int init_expert_ffn_fused_fp8_kernels() {
   static bool done = false;
