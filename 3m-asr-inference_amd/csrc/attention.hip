@@ -404,11 +404,11 @@ __global__ __launch_bounds__(256) void relpos_attention_bf16_kernel(const bf16_t
 bool relpos_attention_bf16_supports(int T, int dk) { return T <= kAttTP && (dk == 64 || dk == 128); }
 
 int init_relpos_attention_bf16_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)relpos_attention_bf16_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, att16_lds_bytes<64>()));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)relpos_attention_bf16_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, att16_lds_bytes<128>()));
-  done = true;
+  once.mark();
   return 0;
 }
 

@@ -77,6 +77,27 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// ---- host-side per-device state.  hipFuncSetAttribute and the CU count belong to a device, not to the process: a process that
+//      drives several devices (tests, a server with one engine per GPU) must set kernel attributes once on EACH of them. ----
+struct PerDeviceOnce {                              // "has this initialisation run on the current device yet?"
+  unsigned long long mask = 0;
+  static int current() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 ? dev : 0;
+  }
+  bool done() const { return (mask >> current()) & 1ull; }
+  void mark() { mask |= 1ull << current(); }
+};
+inline int device_cu_count() {                      // CUs of the current device (256 when there is none: host-side size queries)
+  static int cached[64] = {0};
+  const int dev = PerDeviceOnce::current();
+  if (!cached[dev]) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // Weights that a launch reads exactly once (the skinny GEMMs and the B=1 expert kernel stream 1-107 MB of them per launch).

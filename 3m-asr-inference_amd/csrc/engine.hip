@@ -949,7 +949,9 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     GemmParams pp;
     pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
     if (c.fold_pos_proj) {
-      std::shared_ptr<float> pf = e->pfold_by_tp[Tp].lock();
+      for (auto it = e->pfold_by_tp.begin(); it != e->pfold_by_tp.end();)      // tables no binding holds any more
+        it = it->second.expired() ? e->pfold_by_tp.erase(it) : std::next(it);
+      std::shared_ptr<float> pf = e->pfold_by_tp.count(Tp) ? e->pfold_by_tp[Tp].lock() : nullptr;
       if (!pf) {
         float* dev = nullptr;
         M3_CHECK_HIP(hipMalloc((void**)&dev, (size_t)Tp * nb * D * sizeof(float)));

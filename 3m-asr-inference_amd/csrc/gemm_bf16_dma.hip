@@ -384,14 +384,14 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_dma_kernel
 }
 
 int init_gemm_bf16_dma_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
 #define M3_DMA_ATTR(G_, L_)                                                                                                     \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(2))); \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<G_, L_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(4)))
   M3_DMA_ATTR(false, false); M3_DMA_ATTR(false, true); M3_DMA_ATTR(true, false); M3_DMA_ATTR(true, true);
 #undef M3_DMA_ATTR
-  done = true;
+  once.mark();
   return 0;
 }
 
@@ -420,11 +420,7 @@ int launch_gemm_bf16_dma(const GemmParams& pin, hipStream_t stream) {
   p.n_tiles = gemm_bf16_dma_col_tiles(p);
   dim3 grid(cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
   // work-groups that do not outnumber the CUs: one per CU with a 4-stage ring; else two per CU with 2 stages each
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n;
-  }();
+  const int cus = device_cu_count();
   const bool deep = (long)p.m_tiles * p.n_tiles <= cus && p.K / DBK >= 4;
 #define M3_DMA_LAUNCH(G_, L_)                                                                                              \
   do {                                                                                                                     \

@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
 #define M3_TILED_FOR_ALL(X) \
   X(false, true, false) X(true, false, true) X(true, false, false) X(false, false, true) X(false, false, false)
 int init_gemm_bf16_tiled_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
 #define M3_TILED_ATTR(G_, C_, L_)                                                                                 \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_tiled_kernel<128, 128, 64, G_, C_, L_, 0>,            \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(128, 128, 64)));   \
@@ -430,7 +430,7 @@ int init_gemm_bf16_tiled_kernels() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, tiled_lds_bytes(BM_, BN_, BK_)))
   M3_GRP8_ATTR(128, 128, 64, 1); M3_GRP8_ATTR(128, 128, 64, 2); M3_GRP8_ATTR(64, 64, 128, 1); M3_GRP8_ATTR(64, 64, 128, 2);
 #undef M3_GRP8_ATTR
-  done = true;
+  once.mark();
   return 0;
 }
 

@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int init_gemm_f32_splitk_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_splitk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_splitk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-  done = true;
+  once.mark();
   return 0;
 }
 

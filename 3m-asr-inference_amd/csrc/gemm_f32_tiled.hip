@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_tiled_kernel(const GemmParams
 #define M3_F32D_FOR_ALL(X) \
   X(false, true, false) X(true, false, true) X(true, false, false) X(false, false, true) X(false, false, false)
 int init_gemm_f32_tiled_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
 #define M3_F32D_ATTR(G_, C_, L_)                                                                              \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f32_tiled_kernel<128, 128, 32, G_, C_, L_>,              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, f32d_lds_bytes(128, 128, 32))); \
@@ -284,7 +284,7 @@ int init_gemm_f32_tiled_kernels() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, f32d_lds_bytes(64, 64, 64)));
   M3_F32D_FOR_ALL(M3_F32D_ATTR)
 #undef M3_F32D_ATTR
-  done = true;
+  once.mark();
   return 0;
 }
 

@@ -221,13 +221,13 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_f32_kerne
 // Opt the big-tile variants into > 64 KB of dynamic LDS once (not a stream operation: must not
 // happen inside a hipGraph capture, so the engine calls this at prepare time).
 int init_expert_ffn_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
+  once.mark();
   return 0;
 }
 

@@ -196,10 +196,10 @@ const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F) {
 }
 
 int init_expert_ffn_bf16_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_bf16w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
+  once.mark();
   return 0;
 }
 

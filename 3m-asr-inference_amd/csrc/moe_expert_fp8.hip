@@ -166,10 +166,10 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_w8_kernel
 }
 
 int init_expert_ffn_w8_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_w8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
+  once.mark();
   return 0;
 }
 

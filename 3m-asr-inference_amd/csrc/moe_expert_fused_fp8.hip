@@ -719,13 +719,8 @@ static int fused8_min_rows() {   // read once: the engine freezes the form (and 
 }
 // persistent grid: one work-group per CU, a multiple of 8 (XCDs)
 static int fused8_grid() {
-  static int g = 0;
-  if (!g) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    g = cus >= 8 ? cus / 8 * 8 : 8;
-  }
-  return g;
+  const int cus = device_cu_count();
+  return cus >= 8 ? cus / 8 * 8 : 8;
 }
 int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F) {
   static const int forced = [] { const char* e = getenv("M3_FUSED8_FSPLIT"); return e ? atoi(e) : 0; }();
@@ -753,12 +748,12 @@ bool expert_ffn_fused_fp8_applies(int S, int E, int D, int F) {
   return F % (128 * fs) == 0 && F / fs <= 1024;
 }
 int init_expert_ffn_fused_fp8_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  done = true;
+  once.mark();
   return 0;
 }
 

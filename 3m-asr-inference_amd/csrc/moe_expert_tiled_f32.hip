@@ -204,14 +204,14 @@ float* expert_ffn_f32_rows(float* slab, int S, int E, int D, int F) {
 int expert_ffn_f32_slices(int S, int E, int D, int F) { return expert_ffn_f32_tiled(S, E, D, F) ? 1 : F / kExpertSlice; }
 
 int init_expert_ffn_f32_tiled_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
 #define M3_F32T_ATTR(BM_, BN_, BK_, P_)                                                                      \
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_gemm_f32_tiled_kernel<BM_, BN_, BK_, P_>,              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, f32_tiled_lds_bytes(BM_, BN_, BK_)))
   M3_F32T_ATTR(128, 128, 32, 1); M3_F32T_ATTR(128, 128, 32, 2); M3_F32T_ATTR(64, 64, 64, 1); M3_F32T_ATTR(64, 64, 64, 2);
 #undef M3_F32T_ATTR
-  done = true;
+  once.mark();
   return 0;
 }
 

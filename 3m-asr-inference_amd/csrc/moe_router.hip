@@ -201,13 +201,13 @@ static size_t router_lds_bytes(int De, int D, int NT) {
 }
 
 int init_moe_router_kernels() {
-  static bool done = false;
-  if (done) return 0;
+  static PerDeviceOnce once;
+  if (once.done()) return 0;
   const int big = (int)router_lds_bytes(1024, 1024, 4);
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)moe_router_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)moe_router_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)moe_router_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-  done = true;
+  once.mark();
   return 0;
 }
 

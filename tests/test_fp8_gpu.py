@@ -97,7 +97,8 @@ def test_fmoe_expert_fp8(S, E, D, Fh, mode):
 
 
 def _q8(t):
-    """round-to-nearest-even to e4m3 after clamping to +-448 (what the kernel's v_med3 + v_cvt_pk_fp8_f32 do), in fp64"""
+    """round-to-nearest-even to e4m3, saturating at +-448 (the kernel: v_cvt_pk_fp8_f32 under MODE.FP16_OVFL -- the conversion
+    itself saturates, tools/ubench/fp8_cvt_sat.hip), in fp64"""
     return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double()
 
 
