@@ -124,6 +124,14 @@ struct m3_engine {
 
 namespace {
 
+// rows up to which SoftmaxTopK + ScatterMapping run as ONE single-work-group launch (beyond: row-parallel top-1 + index kernel).
+// M3_GATE_INDEX_MAX_ROWS overrides (read once).  A/B at configs[2] (1984 padded rows): 2048 -> 315 instead of 333 launches but
+// 3.856 vs 3.794 ms per forward (one work-group walks 1984 x 32 logits): the default stays 512.
+int gate_index_max_rows() {
+  static const int v = [] { const char* e = getenv("M3_GATE_INDEX_MAX_ROWS"); return e ? atoi(e) : 512; }();
+  return v;
+}
+
 // dtype: what the engine will read the tensor as (GEMM weights follow cfg.weight_dtype, everything else is fp32)
 bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const float** out, int dtype = M3_F32) {
   auto it = e->table.find(name);
@@ -650,7 +658,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       float *wire_a = pl.wire_a, *wire_b = pl.wire_b;
       const MoeWorkspace rw = carve_moe_workspace(mws, R, E, D, F);     // receive side: R wire rows over the E local experts
       // top-1 + local index over GLOBAL expert ids (the same kernel choice by row count as with all experts local)
-      const bool one_launch = S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
+      const bool one_launch = S <= gate_index_max_rows() && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
       if (one_launch) {
         add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
           return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, g_map, g_acc, g_pos, s);
@@ -705,7 +713,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       e->cur.buffers["ep.wire_b"] = Buf{wire_b, (size_t)R * D * 4};
     } else {
     // "moe_local.*": index + grouped expert FFN + combine with all experts local
-    if (S <= 512 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
+    if (S <= gate_index_max_rows() && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch (a single workgroup: right for a
       // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
