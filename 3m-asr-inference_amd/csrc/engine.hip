@@ -669,12 +669,11 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         }, stage_info("softmax_top1_kernel", 1, (double)S * (Etot * 4 + 8), 0.0));
       }
       // wire row of every token (+ count headers), rows scattered straight into the send wire
-      add_stage(e, pfx + "moe_ep.send", one_launch ? 2 : 3, [=](hipStream_t s) {
+      add_stage(e, pfx + "moe_ep.send", one_launch ? 1 : 2, [=](hipStream_t s) {
         if (!one_launch)
           if (int rc = launch_moe_index(gidx, S, Etot, g_map, g_acc, g_pos, s)) return rc;
-        if (int rc = launch_ep_send_map(gidx, g_map, g_acc, S, world, E, cap, map_send, wire_a, D * 4, s)) return rc;
-        return launch_local_scatter(xn, map_send, S, D * 4, wire_a, s);
-      }, stage_info("row_permute_kernel", one_launch ? 2 : 3, (double)S * D * 8 + 24.0 * S, 0.0));
+        return launch_ep_send_rows(gidx, g_map, g_acc, S, world, E, cap, map_send, xn, wire_a, D * 4, s);
+      }, stage_info("ep_send_rows_kernel", one_launch ? 1 : 2, (double)S * D * 8 + 24.0 * S, 0.0));
       if (world == 1) add_stage(e, pfx + "moe_ep.exchange1", 0, [=](hipStream_t s) {   // one rank: the all-to-all is a copy
         M3_CHECK_HIP(hipMemcpyAsync(wire_b, wire_a, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
         return 0;
@@ -688,9 +687,13 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       const int elaunches = e16 ? expert_ffn_w16_launches(wmode, R, E, D, F) : (expert_ffn_f32_tiled(R, E, D, F) ? 2 : 1);
       const float* erows = e16 ? expert_ffn_w16_rows(wmode, rw.slab, R, E, D, F) : expert_ffn_f32_rows(rw.slab, R, E, D, F);
       const int eslices = e16 ? expert_ffn_w16_slices(wmode, R, E, D, F) : expert_ffn_f32_slices(R, E, D, F);
-      add_stage(e, pfx + "moe_ep.expert", 3 + elaunches, [=](hipStream_t s) {
+      // bf16 experts in the tiled two-GEMM form: GEMM-2's epilogue adds b2 and puts every row straight back on its wire row
+      // (no un-permuting combine launch; wire rows nobody sent keep stale bytes -- no rank ever reads them back)
+      const bool scatter2 = wmode == 1 && expert_ffn_bf16_tiled(R, E, D, F);
+      add_stage(e, pfx + "moe_ep.expert", (scatter2 ? 2 : 3) + elaunches, [=](hipStream_t s) {
         if (int rc = launch_ep_recv_gate(wire_b, world, E, cap, D * 4, gate_recv, s)) return rc;
         if (int rc = launch_moe_index(gate_recv, R, E, rw.mapping, rw.acc, rw.pos, s)) return rc;
+        if (scatter2) return launch_expert_ffn_bf16w(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, eb1, ew2, 1, rw.slab, s, eb2, wire_a);
         int rc;
         if (e8) rc = launch_expert_ffn_w8a8(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, rw.slab, s);
         else if (e16) rc = launch_expert_ffn_bf16w(wire_b, D, rw.pos, rw.acc, R, E, D, F, ew1, eb1, ew2, 1, rw.slab, s);

@@ -45,6 +45,35 @@ __global__ __launch_bounds__(256) void ep_send_map_kernel(const int32_t* __restr
   }
 }
 
+// ep_send_map_kernel + local_scatter in ONE launch (the engine's "moe_ep.send" stage): one wave per token computes the token's
+// wire row, records it in map_send and copies the row there (16 B per lane per access); work-group 0 also writes the headers.
+__global__ __launch_bounds__(256) void ep_send_rows_kernel(const int32_t* __restrict__ gate_idx, const int32_t* __restrict__ mapping,
+                                                           const int32_t* __restrict__ acc, int S, int world, int e_loc, int cap,
+                                                           int32_t* __restrict__ map_send, const uint4* __restrict__ x, int row16,
+                                                           uint4* __restrict__ wire) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < world * e_loc; t += blockDim.x) {
+      const int j = t / e_loc, i = t - j * e_loc;
+      reinterpret_cast<int32_t*>(wire + (size_t)j * (cap + 1) * row16)[i] = acc[t + 1] - acc[t];
+    }
+  for (int s = blockIdx.x * 4 + wave; s < S; s += gridDim.x * 4) {
+    const int g = gate_idx[s];
+    int m = -1;
+    if (g >= 0 && g < world * e_loc) {
+      const int j = g / e_loc;
+      const int off = mapping[s] - acc[j * e_loc];
+      m = off < cap ? j * (cap + 1) + 1 + off : -1;
+    }
+    if (lane == 0) map_send[s] = m;
+    if (m >= 0) {
+      const uint4* src = x + (size_t)s * row16;
+      uint4* dst = wire + (size_t)m * row16;
+      for (int c = lane; c < row16; c += 64) dst[c] = src[c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void ep_recv_gate_kernel(const int32_t* __restrict__ wire, int world, int e_loc, int cap,
                                                            int row_words, int32_t* __restrict__ gate_recv) {
   // one work-group per source rank j
@@ -87,6 +116,18 @@ int launch_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const in
   const int n = S > world * e_loc ? S : world * e_loc;
   hipLaunchKernelGGL(ep_send_map_kernel, dim3(min(cdiv(n, 256), 1024)), dim3(256), 0, stream, gate_idx, mapping, acc_hist, S,
                      world, e_loc, capacity, map_send, (int32_t*)wire, row_bytes / 4);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ep_send_rows(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
+                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream) {
+  M3_REQUIRE(S > 0 && world > 0 && e_loc > 0 && capacity > 0, "ep_send_rows: bad sizes S=%d world=%d e_loc=%d capacity=%d", S,
+             world, e_loc, capacity);
+  M3_REQUIRE((row_bytes & 15) == 0 && row_bytes >= 4 * e_loc, "ep_send_rows: a wire row of %d bytes cannot carry %d counts", row_bytes, e_loc);
+  M3_REQUIRE(capacity >= S, "ep_send_rows: capacity %d < rows %d (a rank may send all of its rows to one peer)", capacity, S);
+  hipLaunchKernelGGL(ep_send_rows_kernel, dim3(min(cdiv(S, 4), 2048)), dim3(256), 0, stream, gate_idx, mapping, acc_hist, S, world,
+                     e_loc, capacity, map_send, (const uint4*)x, row_bytes / 16, (uint4*)wire);
   M3_LAUNCH_CHECK();
   return 0;
 }

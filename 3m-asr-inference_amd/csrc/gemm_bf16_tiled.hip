@@ -322,9 +322,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   constexpr int IT = TBM / (4 * RPI);
   f32x4 res_all[IT];
   bool pad_all[IT];
+  int mo_all[IT];                                   // output row (grouped GEMM-2 with p.y_rows: the row's place in another order)
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, m_end - 1);      // clamped, never branched around
+    mo_all[it] = (GRP == 2 && p.y_rows != nullptr) ? p.y_rows[m] : m0 + (4 * it + wave) * RPI + lane / LPR;
     res_all[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.resid) {
       if (vec_ok) {
@@ -387,11 +389,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       for (int e = 0; e < 4; ++e) h[e] = (bf16_t)y[e];
       *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.Y) + (size_t)m * p.ldy + n) = h;
     } else if (vec_ok) {
-      stg4(p.Y + (size_t)m * p.ldy + n, y);
+      stg4(p.Y + (size_t)mo_all[it] * p.ldy + n, y);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (n + e < Nout) p.Y[(size_t)m * p.ldy + n + e] = y[e];
+        if (n + e < Nout) p.Y[(size_t)mo_all[it] * p.ldy + n + e] = y[e];
     }
   }
 }
@@ -497,7 +499,7 @@ int launch_gemm_bf16w_tiled(const GemmParams& pin, hipStream_t stream) {
 // LayerNorm are applied by moe_combine_kernel with one "slab").  hbuf: S*F bf16, ybuf: S*D fp32.
 int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
                                   int F, const void* w1, const float* b1, const void* w2, int w2_sliced, void* hbuf,
-                                  float* ybuf, hipStream_t stream) {
+                                  float* ybuf, hipStream_t stream, const float* b2, float* y_scatter) {
   M3_REQUIRE((D & 127) == 0 && (F & 127) == 0, "expert_ffn tiled: idim=%d / hidden=%d must be multiples of 128", D, F);
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   // rows per expert ~ S/E: small tiles (4x the workgroups, half the k-steps) until an expert fills 128-row tiles
@@ -514,6 +516,9 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
   g2.M = S; g2.N = D; g2.K = F; g2.w_sliced = w2_sliced;
   g2.grp_acc = acc_hist; g2.grp_E = E;
   g2.n_tiles = cdiv(D, bn); g2.m_tiles = m_slots;
+  if (y_scatter != nullptr) {   // the expert-parallel receive side: + b2, and every sorted row straight back to the wire row it came from
+    g2.Y = y_scatter; g2.y_rows = pos; g2.bias = b2;
+  }
 #define M3_GRP_LAUNCH(BM_, BN_, BK_)                                                                                 \
   do {                                                                                                               \
     hipLaunchKernelGGL((gemm_bf16w_tiled_kernel<BM_, BN_, BK_, false, false, false, 1>), dim3(m_slots * g1.n_tiles), \

@@ -45,6 +45,7 @@ struct GemmParams {
   // packed ragged batches: device-side count of live rows; work-groups whose first row lies beyond it exit (the row AT
   // the count is still computed: it carries the conv module's pad-frame constant, see dwconv_ln_silu_kernel)
   const int32_t* m_dev = nullptr;
+  const int32_t* y_rows = nullptr;                        // grouped GEMM-2 only: output row m goes to row y_rows[m] of Y (expert-parallel: straight to its wire row)
   // implicit conv on a packed ragged batch: valid output frames per utterance; a tile whose rows (b, t2, f2) all lie past
   // the utterance's last frame is skipped (its output rows are never gathered into the packed layout)
   const int32_t* conv_len = nullptr;
@@ -96,6 +97,8 @@ int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_
 // ---- expert-parallel exchange bookkeeping on the device (ep_exchange.hip) ----
 int launch_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
                        int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream);
+int launch_ep_send_rows(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
+                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream);   // send map + scatter, one launch
 int launch_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv,
                         hipStream_t stream);
 
@@ -119,7 +122,7 @@ int launch_expert_ffn_f32_tiled(const float* x, int ldx, const int32_t* pos, con
 int init_expert_ffn_bf16_kernels();
 int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                             int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* slab,
-                            hipStream_t stream);
+                            hipStream_t stream, const float* b2 = nullptr, float* y_scatter = nullptr);   // y_scatter: tiled form only (expert_ffn_bf16_tiled)
 // fp8 (e4m3) expert weights + per-row scales, dequantised to bf16 at the MFMA input (moe_expert_fp8.hip); same result layout as bf16
 int init_expert_ffn_w8_kernels();
 int launch_expert_ffn_w8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
@@ -148,9 +151,11 @@ int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const in
                            const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
                            float h_scale, float* slab, hipStream_t stream);
 // long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
+// b2 / y_scatter (optional): GEMM-2 adds the expert's b2 and writes row i of the sorted order to row pos[i] of y_scatter
+// (the un-permute of the expert-parallel receive side, folded into the epilogue)
 int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,
                                   int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced,
-                                  void* hbuf, float* ybuf, hipStream_t stream);
+                                  void* hbuf, float* ybuf, hipStream_t stream, const float* b2 = nullptr, float* y_scatter = nullptr);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,

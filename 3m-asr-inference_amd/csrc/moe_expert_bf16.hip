@@ -205,14 +205,15 @@ int init_expert_ffn_bf16_kernels() {
 
 int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D,
                             int F, const void* w1, const float* b1, const void* w2, int w2_sliced, float* slab,
-                            hipStream_t stream) {
+                            hipStream_t stream, const float* b2, float* y_scatter) {
   M3_REQUIRE(S > 0 && E > 0, "expert_ffn_bf16w: empty problem S=%d E=%d", S, E);
   M3_REQUIRE((D & 31) == 0 && D <= 2048, "expert_ffn_bf16w: idim=%d must be a multiple of 32 (<=2048)", D);
   M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_bf16w: ldx=%d must be a multiple of 4", ldx);
   if (expert_ffn_bf16_tiled(S, E, D, F))
     return launch_expert_ffn_bf16w_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
-                                         expert_ffn_bf16_rows(slab, S, E, D, F), stream);
+                                         expert_ffn_bf16_rows(slab, S, E, D, F), stream, b2, y_scatter);
+  M3_REQUIRE(y_scatter == nullptr, "expert_ffn_bf16w: the scattering epilogue exists in the tiled form only (S=%d E=%d)", S, E);
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
   const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(bf16_t);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn_bf16w: LDS tile of %zu bytes does not fit", lds_bytes);

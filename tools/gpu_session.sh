@@ -19,7 +19,7 @@ O=gpurun_out/$1; shift
 mkdir -p "$O"
 R=$GRAFT_REPO_ROOT
 CFG3="--weight-dtype bf16 --batch 16 --varlen 50-500 --streams 4"
-CFG5="--weight-dtype fp8 --fp8-activations --experts 64 --batch 64 --varlen 50-500 --streams 2"
+CFG5="--weight-dtype fp8 --fp8-activations --experts 64 --batch 64 --varlen 50-500 --streams 4"
 while [ $# -gt 0 ]; do
   step=$1; shift
   echo "== $step ($(date +%T))"
