@@ -567,6 +567,25 @@ def main():
                             r_["traffic_source"] = "profiles/r03_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe, timed-workload launches only)"
             except Exception:
                 pass
+        # The same kernels' durations as rocprofv3 --kernel-trace --stats saw them over this command (the committed summary of the
+        # workload: profiles/r03_kernel_stats*.csv).  `avg_launch_us` above is a HIP-event pair around each stage on the engine
+        # stream, one forward alone: it contains the dispatch of the launch (~2-3 us); the profiler's figure is the kernel's own
+        # begin -> end (at the bench's context count, i.e. under contention).  Both are reported; `frac` uses the larger, in-situ one.
+        kt_csv = {("f32", 1, 206, 18, 32): "r03_kernel_stats.csv", ("bf16", 16, 500, 18, 32): "r03_kernel_stats_cfg3.csv",
+                  ("fp8", 64, 500, 18, 64): "r03_kernel_stats_cfg5share.csv"}.get((cfg.weight_dtype, B, T, cfg.num_blocks, cfg.num_experts))
+        if kt_csv and os.path.exists(os.path.join(ROOT, "profiles", kt_csv)):
+            try:
+                import csv
+                rows_ = list(csv.DictReader(open(os.path.join(ROOT, "profiles", kt_csv))))
+                for r_ in (roofline, roofline_expert):
+                    base_ = r_["kernel"].split("<")[0]
+                    sel_ = [x for x in rows_ if base_ + "<" in x["Name"] or x["Name"].endswith(base_) or (base_ + "(") in x["Name"]]
+                    if sel_:
+                        calls_ = sum(float(x["Calls"]) for x in sel_)
+                        r_["rocprof_avg_launch_us"] = round(sum(float(x["TotalDurationNs"]) for x in sel_) / calls_ / 1e3, 2)
+                        r_["rocprof_source"] = "profiles/%s (rocprofv3 --kernel-trace --stats over this command)" % kt_csv
+            except Exception:
+                pass
         forward = {"alg_bytes": int(tot_bytes), "flops": int(tot_flops),
                    "latency_ms": {"p50": round(float(np.median(lat)), 4), "p99": round(float(lat[int(0.99 * (len(lat) - 1))]), 4),
                                   "min": round(float(lat[0]), 4), "n": int(len(lat)), "timer": "hipEvent pair per forward, engine stream"},
