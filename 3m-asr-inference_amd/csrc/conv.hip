@@ -142,9 +142,14 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ cmvn_mean,
                                                          const float* __restrict__ cmvn_istd, int T, int idim, int T1,
-                                                         int F1, int C, float* __restrict__ out, int relu, int out_bf16) {
+                                                         int F1, int C, float* __restrict__ out, int relu, int out_bf16,
+                                                         const int32_t* __restrict__ feat_len, int32_t* __restrict__ lens_out, int B) {
   extern __shared__ float xs[];                       // [3][idim]
   const int row = blockIdx.x;                         // b * T1 + t1
+  // the engine's first launch also forms the valid lengths after the two stride-2 convs (both MaskConv2dSample applications,
+  // subsampling.py:119-137) -- one launch less at the head of every forward
+  if (feat_len != nullptr && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < B; i += blockDim.x) lens_out[i] = ((feat_len[i] - 3) / 2 + 1 - 3) / 2 + 1;
   const int b = row / T1, t1 = row - b * T1;
   const float* src = feat + ((size_t)b * T + 2 * t1) * idim;
   for (int i = threadIdx.x; i < 3 * idim; i += blockDim.x) {
@@ -193,7 +198,8 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
 }
 
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
-                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu, int out_bf16) {
+                      const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu, int out_bf16,
+                      const int32_t* feat_len, int32_t* lens_out) {
   M3_REQUIRE(T >= 3 && idim >= 3, "subsampling: input (T=%d, idim=%d) shorter than the 3x3 kernel", T, idim);
   M3_REQUIRE((C & 3) == 0 && C <= 1024, "subsampling: channels=%d must be a multiple of 4 (<= 1024)", C);
   const int T1 = (T - 3) / 2 + 1, F1 = (idim - 3) / 2 + 1;
@@ -201,7 +207,7 @@ int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, co
   const int threads = (int)align_up(C / 4, 64);
   const int fsplit = B * T1 >= 2048 ? 1 : (B * T1 >= 512 ? 2 : 5);
   hipLaunchKernelGGL(conv1_relu_kernel, dim3(B * T1, fsplit), dim3(threads), 3 * idim * sizeof(float), stream,
-                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, relu, out_bf16);
+                     feat, w9c, bias, cmvn_mean, cmvn_istd, T, idim, T1, F1, C, out, relu, out_bf16, feat_len, lens_out, B);
   M3_LAUNCH_CHECK();
   return 0;
 }

@@ -93,6 +93,10 @@ struct m3_engine {
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     bool dma = false;   // a16 and the block GEMMs run on the LDS-DMA kernel: every kernel that writes xb also leaves its row statistics
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
+    // (build-time scratch of the stage list) the next conv1 stage also forms the subsampled lengths; a second LayerNorm
+    // for the next norm_final stage
+    bool lens_in_conv1 = false;
+    const float *tail_ln_g = nullptr, *tail_ln_b = nullptr; float tail_ln_eps = 0.f; float* tail_ln_out = nullptr;
     int ep_cap = 0;        // expert parallel: rows per wire chunk this binding was built for (m3_engine_set_ep_capacity)
     // fork_embed: stages [fork_first, fork_mid) = the embed encoder (side branch of the captured graph), [fork_mid, join_at) =
     // what the main encoder does before it needs the embedding; -1 = one linear chain
@@ -435,7 +439,11 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
   const int idim = c.input_dim;
   const float* cm = e->cmvn_mean; const float* ci = e->cmvn_istd;
   const bool a16 = e->cur.a16;    // c1, c2 only feed GEMMs: kept as bf16; the Linear also writes the bf16 copy of x
-  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s, 1, a16); },
+  // (the forward's first conv1 also forms the subsampled lengths when no stage in front of it needs them: see "lens" below)
+  const int32_t* flen = e->cur.lens_in_conv1 ? e->cur.feat_len : nullptr;
+  int32_t* lens_out = pl.lens;
+  e->cur.lens_in_conv1 = false;
+  add_stage(e, pfx + "conv1", 1, [=](hipStream_t s) { return launch_conv1_relu(feat, w.c1w, w.c1b, cm, ci, B, T, idim, D, c1, s, 1, a16, flen, lens_out); },
             stage_info("conv1_relu_kernel", 1, (double)B * T * idim * 4 + (double)B * T1 * F1 * D * (a16 ? 2 : 4), 18.0 * B * T1 * F1 * D, false));
   GemmParams g;
   g.a_bf16 = a16; g.y_bf16 = a16;
@@ -583,8 +591,12 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     void* xbo = a16 ? xb : nullptr;
     float* xso = dma ? xstats : nullptr;
-    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo, xso); },
-              stage_info("layernorm_kernel", 1, (double)S * D * (a16 ? 10 : 8), 8.0 * S * D));
+    // (the embed encoder's last block: after_norm rides in the same launch, conformer_embed_domain_acc.py:171-181)
+    const float* g2 = e->cur.tail_ln_g; const float* b2 = e->cur.tail_ln_b; float* y2 = e->cur.tail_ln_out;
+    const float eps2 = e->cur.tail_ln_eps;
+    e->cur.tail_ln_g = nullptr;
+    add_stage(e, pfx + "norm_final", 1, [=](hipStream_t s) { return launch_layernorm(x, fg, fb, eps, x, S, D, s, xbo, xso, g2, b2, eps2, y2); },
+              stage_info("layernorm_kernel", 1, (double)S * D * (a16 ? 10 : 8) + (g2 ? 4.0 * S * D : 0.0), (g2 ? 16.0 : 8.0) * S * D));
   } else {  // x = LN_final(x + 0.5 * gate * Expert_g(LN(x)))     (positionwise_feed_forward.py:209-265)
     const int world = c.ep_world_size > 0 ? c.ep_world_size : 1;
     const int Etot = c.num_experts * world, E = c.num_experts, De = c.embed_dim;
@@ -944,13 +956,21 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
 
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
   {
+    // No launch of their own: the packed layout's row plan forms them on its way; otherwise the forward's first kernel (the
+    // embed subsampler's conv1) does.  Exceptions that keep the separate "lens" stage: a forked capture (the main branch reads
+    // the lengths while the embed branch, whose conv1 would write them, runs beside it) and a positional projection that is
+    // not folded (its GEMM would sit in front of conv1 -- harmless, but the stage order of round 1 is kept for it).
     int32_t* lens = pl.lens;
-    add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); },
-              stage_info("subsample_lens_kernel", 1, 8.0 * B, 0.0, false));
+    e->cur.lens_in_conv1 = false;
     if (e->cur.packed) {   // row plan of the packed layout: first row of every utterance, packed -> padded row map
       int32_t* row0 = pl.row0; int32_t* pad_of = pl.pad_of;
-      add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s); },
-                stage_info("pack_plan_kernel", 1, 8.0 * B + 4.0 * B * Tp, 0.0, false));
+      add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s, feat_len); },
+                stage_info("pack_plan_kernel", 1, 12.0 * B + 4.0 * B * Tp, 0.0, false));
+    } else if (pl.fork || !c.fold_pos_proj) {
+      add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); },
+                stage_info("subsample_lens_kernel", 1, 8.0 * B, 0.0, false));
+    } else {
+      e->cur.lens_in_conv1 = true;
     }
   }
   // ---- p = linear_pos(pe[:T']) for all blocks at once (attention.py:345; input-independent, so with
@@ -984,11 +1004,15 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   if (pl.fork) e->cur.fork_first = (int)e->cur.stages.size();
   e->cur.splitk_ws = ple.splitk;
   build_subsample(e, "embed.subsample.", e->sub_e, De, ple, ple.x);
-  for (int i = 0; i < c.embed_blocks; ++i)
+  for (int i = 0; i < c.embed_blocks; ++i) {
+    if (i + 1 == c.embed_blocks) {   // after_norm joins the last block's norm_final launch
+      e->cur.tail_ln_g = e->e_after.g; e->cur.tail_ln_b = e->e_after.b; e->cur.tail_ln_eps = 1e-12f; e->cur.tail_ln_out = pl.emb;
+    }
     build_block(e, "embed.blocks." + std::to_string(i) + ".", e->eblocks[i], De, c.embed_linear_units, c.embed_heads,
                 c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, ple);
+  }
   e->cur.splitk_ws = pl.splitk;
-  {
+  if (c.embed_blocks == 0) {
     float* x = ple.x; float* emb = pl.emb;
     const float* g = e->e_after.g; const float* b = e->e_after.b;
     add_stage(e, "embed.after_norm", 1, [=](hipStream_t s) { return launch_layernorm(x, g, b, 1e-12f, emb, S, De, s); },

@@ -164,7 +164,8 @@ int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, 
 
 // ---- row-wise ops (rowops.hip) ----
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream, void* y_bf16 = nullptr, float* y_stats = nullptr);
+                     hipStream_t stream, void* y_bf16 = nullptr, float* y_stats = nullptr, const float* gamma2 = nullptr,
+                     const float* beta2 = nullptr, float eps2 = 0.f, float* y2 = nullptr);   // gamma2: y2 = LN2(LN1(x)) in the same launch
 int launch_softmax_top1(const float* logits, int ld, const int32_t* row_len, int rows_per_batch, int S, int E,
                         int32_t* idx, float* value, hipStream_t stream);
 int launch_att_masked_softmax(const float* scores, const int32_t* len, int B, int H, int T1, int T2, float scale,
@@ -206,11 +207,12 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
                           int out_bf16 = 0, const int32_t* pad_of = nullptr, const int32_t* row0 = nullptr,
                           const int32_t* row_len = nullptr);
 // packed (padding-free) rows of a ragged batch (rowops.hip): plan from the valid lengths; padded output from packed rows
-int launch_pack_plan(const int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream);
+int launch_pack_plan(int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream,
+                     const int32_t* feat_len = nullptr);   // feat_len: form the subsampled lengths here too (len becomes an output)
 int launch_unpack_rows(const float* in, const int32_t* row0, int B, int T, int n, float* out, hipStream_t stream);
 int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, const float* cmvn_mean,
                       const float* cmvn_istd, int B, int T, int idim, int C, float* out, hipStream_t stream, int relu = 1,
-                      int out_bf16 = 0);
+                      int out_bf16 = 0, const int32_t* feat_len = nullptr, int32_t* lens_out = nullptr);   // feat_len: also the subsampled lengths
 int launch_cmvn(const float* x, const int32_t* len, const float* mean, const float* istd, int B, int T, int D,
                 float* y, hipStream_t stream);
 int launch_log_softmax_bias(const float* x, const float* bias, float* y, size_t rows, int n, hipStream_t stream);

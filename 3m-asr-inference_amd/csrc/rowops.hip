@@ -17,10 +17,15 @@
 namespace m3 {
 
 // ---------------------------------------------------------------- LayerNorm (one wave per row)
+// gamma2 != null: a SECOND LayerNorm applied to the first one's result, y2 = LN2(LN1(x)) -- the embed encoder ends in
+// norm_final of its last block followed by after_norm (conformer_embed_domain_acc.py:171-181): one launch, same arithmetic
+// (LN2's statistics are taken from the fp32 values LN1 stores).
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* y, int rows, int D, bf16_t* yb, float* ystats) {  // y may alias x (row-local)
+                                                        float* y, int rows, int D, bf16_t* yb, float* ystats,
+                                                        const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                        float eps2, float* __restrict__ y2) {  // y may alias x (row-local)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       stg4(y + (size_t)row * D + c, o);
+      v[i] = o;                                       // (kept for the optional second LayerNorm)
       if (yb != nullptr) {                            // bf16 copy for the next GEMMs' A operand
         bf16x4 h;
 #pragma unroll
@@ -77,6 +83,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     t1 = wave_sum(t1);
     t2 = wave_sum(t2);
     if (lane < 2 * kXbStatParts) ystats[(size_t)row * 2 * kXbStatParts + lane] = lane == 0 ? t1 : (lane == 1 ? t2 : 0.f);
+  }
+  if (gamma2 != nullptr) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean2 = wave_sum(s2) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = v[i][j] - mean2;
+          q2 += d * d;
+        }
+      }
+    }
+    const float rstd2 = rsqrtf(wave_sum(q2) / (float)D + eps2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+        const f32x4 g = ldg4(gamma2 + c), b = ldg4(beta2 + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean2) * rstd2 * g[j] + b[j];
+        stg4(y2 + (size_t)row * D + c, o);
+      }
+    }
   }
 }
 
@@ -109,13 +148,16 @@ int launch_row_stats_bf16(const void* xb, int rows, int D, float* stats, hipStre
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,
-                     hipStream_t stream, void* y_bf16, float* y_stats) {
+                     hipStream_t stream, void* y_bf16, float* y_stats, const float* gamma2, const float* beta2, float eps2,
+                     float* y2) {
+  M3_REQUIRE(gamma2 == nullptr || (beta2 != nullptr && y2 != nullptr), "layernorm: the second LayerNorm needs beta2 and y2");
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "layernorm: dim=%d must be a multiple of 4 (<=2048)", D);
   if (rows == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(rows, 4));
 #define M3_LN_CASE(NV_) \
-  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D, (bf16_t*)y_bf16, y_stats)
+  hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, stream, x, gamma, beta, eps, y, rows, D, (bf16_t*)y_bf16, y_stats, \
+                     gamma2, beta2, eps2, y2)
   if (nv <= 1) M3_LN_CASE(1); else if (nv <= 2) M3_LN_CASE(2); else if (nv <= 4) M3_LN_CASE(4); else M3_LN_CASE(8);
 #undef M3_LN_CASE
   M3_LAUNCH_CHECK();
@@ -466,14 +508,21 @@ int launch_subsample_lens(const int32_t* len_in, int B, int32_t* len_out, hipStr
 // ---------------------------------------------------------------- packed (padding-free) row plan of a ragged batch
 // len [B] valid frames per utterance (<= T) -> row0 [B+1] exclusive prefix (row0[B] = P, the packed row count) and
 // pad_of [B*T]: packed row p -> its row b*T + t in the padded layout, -1 for p >= P.  One work-group.
-__global__ __launch_bounds__(256) void pack_plan_kernel(const int32_t* __restrict__ len, int B, int T,
-                                                        int32_t* __restrict__ row0, int32_t* __restrict__ pad_of) {
+// feat_len != null: `len` is an OUTPUT too -- the subsampled lengths are formed here from the raw feature lengths (what
+// subsample_lens_kernel does), so that a packed forward starts with one launch instead of two.
+__global__ __launch_bounds__(256) void pack_plan_kernel(int32_t* __restrict__ len, int B, int T, int32_t* __restrict__ row0,
+                                                        int32_t* __restrict__ pad_of, const int32_t* __restrict__ feat_len) {
   __shared__ int start[1025];
   if (threadIdx.x == 0) {
     int run = 0;
     for (int b = 0; b < B; ++b) {
       start[b] = run;
-      run += min(max(len[b], 0), T);
+      int l = len[b];
+      if (feat_len != nullptr) {
+        l = ((feat_len[b] - 3) / 2 + 1 - 3) / 2 + 1;
+        len[b] = l;
+      }
+      run += min(max(l, 0), T);
     }
     start[B] = run;
   }
@@ -486,9 +535,9 @@ __global__ __launch_bounds__(256) void pack_plan_kernel(const int32_t* __restric
     if (i >= P) pad_of[i] = -1;          // disjoint from the writes above (those go to rows < P)
   }
 }
-int launch_pack_plan(const int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream) {
+int launch_pack_plan(int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream, const int32_t* feat_len) {
   M3_REQUIRE(B > 0 && B <= 1024 && T > 0, "pack_plan: batch %d out of range [1,1024]", B);
-  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), 0, stream, len, B, T, row0, pad_of);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(256), 0, stream, len, B, T, row0, pad_of, feat_len);
   M3_LAUNCH_CHECK();
   return 0;
 }

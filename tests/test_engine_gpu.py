@@ -106,7 +106,9 @@ def test_engine_forked_embed_branch_is_bit_identical(B, wdt):
         forked.stream.synchronize()
         assert torch.equal(forked._bound[2], eager)
     assert forked.workspace_size(B, T) > chain.workspace_size(B, T)   # the embed branch's scratch
-    assert forked.num_kernels() == chain.num_kernels()
+    # the same kernels -- plus, on unpacked rows, the separate length kernel: in one chain the first conv1 forms the subsampled
+    # lengths on its way, in a forked graph the main branch reads them while the embed branch's conv1 runs beside it
+    assert forked.num_kernels() - chain.num_kernels() == (0 if chain.packed_rows() else 1)
 
 
 def test_fused_and_staged_route_paths_agree():
