@@ -199,7 +199,10 @@ bool moe_router_supports(int De, int D, int N) {
   return N >= 1 && N <= 64 && (De & 63) == 0 && (D & 63) == 0 && De >= 64 && D >= 64 && De <= 1024 && D <= 1024;
 }
 
-constexpr size_t kRouterLdsFloor = 96 * 1024;
+#ifndef M3_ROUTER_LDS_FLOOR
+#define M3_ROUTER_LDS_FLOOR (96 * 1024)      // (-DM3_ROUTER_LDS_FLOOR=0: the two-per-CU form, for tests/test_concurrent_gpu.py's history only)
+#endif
+constexpr size_t kRouterLdsFloor = M3_ROUTER_LDS_FLOOR;
 static size_t router_lds_bytes(int De, int D, int NT) {
   const size_t tiles = (size_t)16 * (De + 8 + D + 8) * 4, red = (size_t)4 * NT * 256 * 4;
   return tiles > red ? tiles : red;
