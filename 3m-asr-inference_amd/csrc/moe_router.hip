@@ -200,7 +200,7 @@ bool moe_router_supports(int De, int D, int N) {
 }
 
 #ifndef M3_ROUTER_LDS_FLOOR
-#define M3_ROUTER_LDS_FLOOR (96 * 1024)      // (-DM3_ROUTER_LDS_FLOOR=0: the two-per-CU form, for tests/test_concurrent_gpu.py's history only)
+#define M3_ROUTER_LDS_FLOOR 0
 #endif
 constexpr size_t kRouterLdsFloor = M3_ROUTER_LDS_FLOOR;
 static size_t router_lds_bytes(int De, int D, int NT) {
@@ -230,11 +230,10 @@ int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx
   const int tiles = cdiv(N, 16), rows16 = cdiv(M, 16);
   int nt = tiles <= 1 ? 1 : (tiles == 2 ? 2 : 4);
   while (nt > 1 && (long)rows16 * cdiv(tiles, nt) < 192) nt >>= 1;
-  // ONE work-group per CU (the request exceeds half of the CU's 160 KB): with two of them resident on a CU, work-groups of
-  // DIFFERENT launches (execution contexts running side by side) produced, about once in 200 forwards, a row whose LayerNorm
-  // mean was off by ~1e-2 -- right inputs, right registers (an in-kernel re-check of the sum never disagreed), wrong mean, with
-  // DPP and with ds_bpermute reductions alike; never with one work-group per CU (0 of 1600 forwards), never with one context.
-  // Root cause not found; tests/test_concurrent_gpu.py pins the behaviour.
+  // Two work-groups per CU.  (Round 3 found this kernel returning, about once in 100 forwards under concurrent execution
+  // contexts, a row whose LayerNorm mean was wrong: packed-FP32 VALU instructions of a wave in phase 1 next to the MFMAs of a
+  // work-group of ANOTHER launch on the same SIMD -- DESIGN.md 10.8.  The library is built without those instructions (Makefile:
+  // NOPK); -DM3_ROUTER_LDS_FLOOR=98304 restores the interim fix, one work-group per CU.)
   size_t lds = router_lds_bytes(De, D, nt);
   if (lds < kRouterLdsFloor) lds = kRouterLdsFloor;
   dim3 grid(rows16, cdiv(tiles, nt));
