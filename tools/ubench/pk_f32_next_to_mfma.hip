@@ -14,18 +14,41 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void roles_kernel(const float* __restrict__ in, unsigned* __restrict__ bad, int iters, int mode) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
-  const bool mfma_role = mode == 1 && (blockIdx.x & 1);
+  const bool mfma_role = mode >= 1 && (blockIdx.x & 1);
   if (mfma_role) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    float a = in[threadIdx.x], b = in[threadIdx.x + 256];
-    for (int i = 0; i < iters * 4; ++i) {
+    if (mode == 1) {                                       // fp32 MFMA, registers only
+      float a = in[threadIdx.x], b = in[threadIdx.x + 256];
+      for (int i = 0; i < iters * 4; ++i) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+    } else {                                               // bf16 MFMA; mode 3: operands re-read from LDS, which is re-written from memory
+      bf16x8 a, b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] = (__bf16)in[threadIdx.x + e]; b[e] = (__bf16)in[threadIdx.x + 8 + e]; }
+      bf16x8* l = reinterpret_cast<bf16x8*>(lds);
+      l[threadIdx.x] = a; l[256 + threadIdx.x] = b;
+      __syncthreads();
+      for (int i = 0; i < iters; ++i) {
+        if (mode == 3) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(in + ((size_t)((i * 256 + threadIdx.x) % 4096)) * 4);
+          bf16x8 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { w[e] = (__bf16)g0[e]; w[4 + e] = (__bf16)g0[e]; }
+          l[512 + ((i & 7) * 256) + threadIdx.x] = w;
+          a = l[(threadIdx.x + i) & 255];
+          b = l[256 + ((threadIdx.x + 2 * i) & 255)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+      }
     }
     if (acc[0] == 1234567.f) bad[1] = 1;                  // (keeps the chain alive)
     return;
@@ -69,9 +92,9 @@ int main() {
   const int lds = 70 * 1024;
   CHECK(hipFuncSetAttribute((const void*)roles_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   CHECK(hipFuncSetAttribute((const void*)roles_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const char* names[2] = {"sums next to sums", "sums next to MFMAs"};
+  const char* names[4] = {"sums next to sums", "sums next to fp32 MFMAs", "sums next to bf16 MFMAs", "... + LDS / loads"};
   for (int packed = 1; packed >= 0; --packed)
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       CHECK(hipMemset(bad, 0, 16));
       for (int rep = 0; rep < 20; ++rep) {
         if (packed) hipLaunchKernelGGL(roles_kernel<true>, dim3(2048), dim3(256), lds, 0, in, bad, 20000, mode);
@@ -80,7 +103,7 @@ int main() {
       CHECK(hipDeviceSynchronize());
       unsigned hb[4];
       CHECK(hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost));
-      printf("%-8s adds, %-20s: %u sums differ from the first one of their lane (%.1f G sums)\n", packed ? "packed" : "scalar", names[mode], hb[0],
+      printf("%-8s adds, %-24s: %u sums differ from the first one of their lane (%.1f G sums)\n", packed ? "packed" : "scalar", names[mode], hb[0],
              20.0 * 2048 * (mode ? 0.5 : 1.0) * 256 * 20000 / 1e9);
     }
   return 0;
