@@ -230,10 +230,11 @@ int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx
   const int tiles = cdiv(N, 16), rows16 = cdiv(M, 16);
   int nt = tiles <= 1 ? 1 : (tiles == 2 ? 2 : 4);
   while (nt > 1 && (long)rows16 * cdiv(tiles, nt) < 192) nt >>= 1;
-  // Two work-groups per CU.  (Round 3 found this kernel returning, about once in 100 forwards under concurrent execution
-  // contexts, a row whose LayerNorm mean was wrong: packed-FP32 VALU instructions of a wave in phase 1 next to the MFMAs of a
-  // work-group of ANOTHER launch on the same SIMD -- DESIGN.md 10.8.  The library is built without those instructions (Makefile:
-  // NOPK); -DM3_ROUTER_LDS_FLOOR=98304 restores the interim fix, one work-group per CU.)
+  // Two work-groups per CU.  (Round 3: under concurrent execution contexts this kernel returned, about once in 100 forwards,
+  // a row whose LayerNorm mean was wrong -- only beside two particular LDS-DMA GEMM launches of ANOTHER context, only when
+  // built with packed-FP32 VALU instructions.  Symptom eliminated by building the library without them (Makefile NOPK,
+  // asserted on the built code by tools/check_device_isa.py); the mechanism is open, DESIGN.md 10.8.
+  // -DM3_ROUTER_LDS_FLOOR=98304 restores the structural guard, one work-group per CU.)
   size_t lds = router_lds_bytes(De, D, nt);
   if (lds < kRouterLdsFloor) lds = kRouterLdsFloor;
   dim3 grid(rows16, cdiv(tiles, nt));

@@ -25,6 +25,16 @@ def lib_path():
     return _lib.LIB_PATH
 
 
+def test_device_code_has_no_packed_fp32(lib_path):
+    """the library is built without v_pk_{add,mul,fma}_f32 (Makefile NOPK).  The flag is a -target-feature the
+    host half of the compile 'ignores' with a warning, so the property is asserted on the BUILT gfx950 code objects."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_device_isa
+    r = check_device_isa.assert_no_packed_fp32(lib_path)
+    assert r["code_objects"] >= 15 and r["instructions"] > 100000, r
+
+
 def test_header_symbols_are_exported(lib_path):
     lib = ctypes.CDLL(lib_path)
     names = _declared()

@@ -2,9 +2,10 @@
 
 bench.py's `value` is measured with four contexts in flight, and an expert-parallel rehearsal steps eight engines at once: a
 kernel whose result depends on what else is resident on its CU would make those numbers meaningless.  Round 3 had such a kernel
-(moe_router_kernel: about one forward in 100 came back with one row whose LayerNorm mean was off by 1e-2 -- packed-FP32 VALU
-instructions next to another launch's MFMAs on the same SIMD; the library is built without those instructions
-since); this test is what found it and what keeps it fixed.  Every case: N contexts (own stream, workspace and
+(moe_router_kernel: about one forward in 100 came back with one row whose LayerNorm mean was off by 1e-2 -- only when built
+with packed-FP32 VALU instructions and only beside two LDS-DMA GEMM launches of another context; the library is built without
+those instructions since, which removes the symptom; the mechanism is open); this test is what found it and
+the statistical half of the guard (the deterministic half: tests/test_abi.py::test_device_code_has_no_packed_fp32).  Every case: N contexts (own stream, workspace and
 input; shared weights), serial results first, then rounds with all contexts enqueued before any synchronisation."""
 import os
 
