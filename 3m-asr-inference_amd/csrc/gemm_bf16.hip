@@ -299,6 +299,10 @@ int launch_gemm_bf16w(const GemmParams& pin, hipStream_t stream) {
   M3_REQUIRE(!(ln && p.mask_in) || p.ln_wbeta, "gemm_bf16w: folded LayerNorm + input mask needs ln_wbeta");
   if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm_bf16w: mask needs row_len");
   if (gemm_bf16w_uses_dma(p)) return launch_gemm_bf16_dma(p, stream);
+  // only the LDS-DMA kernel writes / reads the row-statistic partials: a consumer of y_copy_stats would read stale numbers
+  M3_REQUIRE(p.Yb_stats == nullptr && p.ln_stats == nullptr,
+             "gemm_bf16w: y_copy_stats / ln_stats need the LDS-DMA kernel (M >= %d rows, bf16 A); this problem (M=%d) runs on another one",
+             dma_min_rows(), p.M);
   if (gemm_bf16w_uses_tiled(p)) return launch_gemm_bf16w_tiled(p, stream);
   M3_REQUIRE(!p.a_bf16 && !p.y_bf16 && p.Yb == nullptr, "gemm_bf16w: bf16 activations are a feature of the tiled kernel");
   const int Nout = glu ? p.N / 2 : p.N;

@@ -46,7 +46,7 @@ constexpr int dma_lds_bytes(int stages) { return stages * kStageBytes > kImageBy
 // LDS-DMA fill, hidden from hipcc's waitcnt pass (see the header): 64 lanes x 16 B land at lds_addr + 16 lane
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, size_t bytes) {
   const unsigned long long a = (unsigned long long)base;

@@ -215,7 +215,9 @@ typedef struct m3_linear_desc {
    *   y_copy_stats: with it, per row and per 128-column tile the (sum, sum of squares) of the bf16 values stored
    *     ([M][N/128][2] floats) -- the row statistics a folded-LayerNorm GEMM needs when its bf16 operand goes to LDS
    *     without passing through registers (LDS-DMA kernel); ln_stats / ln_stat_parts: such statistics of `a` (their parts
-   *     are summed), required with ln_wsum when a_dtype = M3_BF16 and the LDS-DMA kernel is to be used.
+   *     are summed), required with ln_wsum when a_dtype = M3_BF16 and the LDS-DMA kernel is to be used.  Only the LDS-DMA
+   *     kernel (M >= 4096 rows, bf16 A, K % 64 == 0) reads or writes them: a call that passes either and lands on another
+   *     kernel FAILS (non-zero status) rather than leaving stale statistics behind.
    * All zero / NULL = fp32 activations as before. */
   int32_t a_dtype, y_dtype;
   void* y_copy_bf16; int32_t ld_copy;
