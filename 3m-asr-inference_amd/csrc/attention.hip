@@ -207,6 +207,178 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
 
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Chunk-by-chunk (streaming) form: the queries are the C frames of the current chunk, the keys / values are every frame the
+// static chunk mask lets them see -- the chunk itself (still in the QKV GEMM's output) and the frames to its left, which come
+// from the per-layer history `hist` [B][cap][2 D] (K | V rows of all earlier chunks, a ring when cap < the stream's length).
+// This is what the reference's cache plugins were written for: CatSplitCachePluginDynamic concatenates the cached K / V with
+// the chunk's and splits the new cache off (cat_split_cache_kernel.cu:30-107), AttStreamSoftmaxPluginDynamic masks the scores
+// to [ld - decode_frame_num, mask_idx + cache_len) (att_stream_softmax_kernel.cu:136-191), RelPositionalEncoding's streaming
+// form takes pe[offset : offset + T] (rel_positional_encoding_kernel.cu:108-123).  Here they are one kernel: nothing is
+// concatenated or copied, the work-group that owns 16 query frames of a head also appends that head's K / V rows of those
+// frames to the history (read only by LATER chunks: keys of the current chunk are taken from the QKV buffer), and p is
+// indexed by the key's absolute position.  The chunk counter lives on the device (`step`), so the launch is replayable from
+// a hipGraph.  Key tiles sit at absolute multiples of 16 and wave w owns tiles w, w + 4, ... exactly as in the full-utterance
+// kernel above; tiles left of every row's window are skipped (there they leave the softmax state untouched), so a chunk's
+// context equals the rows the full-utterance kernel computes under the same static chunk mask bit for bit.
+template <int DK>
+__global__ __launch_bounds__(256) void relpos_attention_stream_kernel(const float* __restrict__ qkv, int ldq,
+                                                                     float* __restrict__ hist, int cap,
+                                                                     const float* __restrict__ pmat, int ldp,
+                                                                     const float* __restrict__ pos_u, const float* __restrict__ pos_v,
+                                                                     const int32_t* __restrict__ chunk_len, const int32_t* __restrict__ step,
+                                                                     int C, int D, float scale, float* __restrict__ out, int ldo,
+                                                                     int QT, int H, int left_chunks) {
+  constexpr int KS = DK / 16;
+  asm volatile("" ::"s"(qkv), "s"(ldq), "s"(hist), "s"(cap), "s"(pmat), "s"(ldp), "s"(pos_u), "s"(pos_v), "s"(chunk_len), "s"(step),
+               "s"(C), "s"(D), "s"(scale), "s"(out), "s"(ldo), "s"(QT), "s"(H), "s"(left_chunks));
+  __shared__ __attribute__((aligned(16))) float ps_all[4][16][20];
+  __shared__ float mo[4][16][DK + 1];
+  __shared__ float mm[4][16], ml[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kq = lane >> 4;
+  float (*ps)[20] = ps_all[wave];
+  const int bh = blockIdx.x / QT, qt = blockIdx.x - bh * QT;
+  const int b = bh / H, h = bh - b * H, q0 = qt * 16;
+  const int off = *step * C;                              // absolute index of the chunk's first frame
+  const int nlive = min(max(chunk_len[b], 0), C);         // valid frames of utterance b in this chunk
+  const int len = off + nlive;                            // keys the utterance has so far
+  const size_t brow = (size_t)b * C;
+  const float* hb = hist + (size_t)b * cap * 2 * D;
+
+  // ---- this work-group's share of the history append: K | V of head h, frames q0 .. q0 + 15 of the chunk ----
+  for (int idx = threadIdx.x; idx < 16 * 2 * (DK / 4); idx += 256) {
+    const int r = idx / (2 * (DK / 4)), rem = idx - r * 2 * (DK / 4), kv = rem / (DK / 4), c4 = (rem - kv * (DK / 4)) * 4;
+    if (q0 + r < C) {
+      const f32x4 val = ldg4(qkv + (brow + q0 + r) * ldq + (1 + kv) * D + h * DK + c4);
+      stg4(hist + ((size_t)b * cap + (size_t)((off + q0 + r) % cap)) * 2 * D + kv * D + h * DK + c4, val);
+    }
+  }
+
+  const int qi = min(q0 + col, C - 1);
+  const float* qrow = qkv + (brow + qi) * ldq + h * DK + 4 * kq;
+  f32x4 qu[KS], qv[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const f32x4 q4 = ldg4(qrow + 16 * s);
+    qu[s] = q4 + ldg4(pos_u + h * DK + 16 * s + 4 * kq);
+    qv[s] = q4 + ldg4(pos_v + h * DK + 16 * s + 4 * kq);
+  }
+  f32x4 o[KS];
+#pragma unroll
+  for (int n = 0; n < KS; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m_run[r] = -INFINITY;
+    l_run[r] = 0.f;
+  }
+  // every query of the chunk sits in chunk number *step: one window [klo, khi) for all of them
+  const int cidx = off / C;
+  const int klo = left_chunks < 0 ? 0 : max((cidx - left_chunks) * C, 0);
+  const int khi = min((cidx + 1) * C, len);
+  const int last = max(len - 1, 0);
+  for (int j0 = 16 * wave; j0 < len; j0 += 64) {
+    if (j0 + 16 <= klo) continue;                          // wholly left of the window: the full kernel's state is untouched there
+    const int kj = min(j0 + col, last);
+    const float* krow = (kj >= off ? qkv + (brow + kj - off) * ldq + D : hb + (size_t)(kj % cap) * 2 * D) + h * DK + 4 * kq;
+    const float* prow = pmat + (size_t)kj * ldp + h * DK + 4 * kq;
+    f32x4 kb[KS], pb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kb[s] = ldg4(krow + 16 * s);
+      pb[s] = ldg4(prow + 16 * s);
+    }
+    float vb[KS][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int vj = min(j0 + 4 * kq + jj, last);
+      const float* vrow = (vj >= off ? qkv + (brow + vj - off) * ldq + 2 * D : hb + (size_t)(vj % cap) * 2 * D + D) + h * DK + col;
+#pragma unroll
+      for (int n = 0; n < KS; ++n) vb[n][jj] = vrow[16 * n];
+    }
+    f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc = mfma16(qu[s][j], kb[s][j], sc);
+        sc = mfma16(qv[s][j], pb[s][j], sc);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool valid = (j0 + col) >= klo && (j0 + col) < khi;
+      const float sv = valid ? sc[r] * scale : -INFINITY;
+      const float m_new = fmaxf(m_run[r], group16_max(sv));
+      const float pexp = valid ? expf(sv - m_new) : 0.f;
+      const float corr = (m_new == -INFINITY) ? 1.f : expf(m_run[r] - m_new);
+      l_run[r] = l_run[r] * corr + group16_sum(pexp);
+      m_run[r] = m_new;
+#pragma unroll
+      for (int n = 0; n < KS; ++n) o[n][r] *= corr;
+      ps[4 * kq + r][col] = pexp;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(&ps[col][4 * kq]);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < KS; ++n)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) o[n] = mfma16(pa[jj], vb[n][jj], o[n]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (col == 0) {
+      mm[wave][4 * kq + r] = m_run[r];
+      ml[wave][4 * kq + r] = l_run[r];
+    }
+#pragma unroll
+    for (int n = 0; n < KS; ++n) mo[wave][4 * kq + r][16 * n + col] = o[n][r];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * DK; idx += 256) {
+    const int i = idx / DK, d = idx - i * DK;
+    const int qrow = q0 + i;
+    if (qrow >= C) continue;
+    const float m_tot = fmaxf(fmaxf(mm[0][i], mm[1][i]), fmaxf(mm[2][i], mm[3][i]));
+    float l_tot = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = (mm[w][i] == -INFINITY) ? 0.f : expf(mm[w][i] - m_tot);
+      l_tot += ml[w][i] * f;
+      acc += mo[w][i][d] * f;
+    }
+    out[(brow + qrow) * ldo + h * DK + d] = l_tot > 0.f ? acc / l_tot : 0.f;
+  }
+}
+
+int launch_relpos_attention_stream(const float* qkv, int ldq, float* hist, int cap, const float* pmat, int ldp, const float* pos_u,
+                                   const float* pos_v, const int32_t* chunk_len, const int32_t* step, int B, int C, int H, int dk,
+                                   float scale, float* out, int ldo, int left_chunks, hipStream_t stream) {
+  M3_REQUIRE(B > 0 && C > 0 && H > 0 && cap >= C, "attention (stream): empty problem or history shorter than a chunk");
+  M3_REQUIRE(left_chunks < 0 || cap >= (left_chunks + 1) * C, "attention (stream): a history of %d frames cannot hold %d left chunks of %d", cap, left_chunks, C);
+  M3_REQUIRE((ldq & 3) == 0 && (ldp & 3) == 0 && (dk & 3) == 0, "attention (stream): row strides must be multiples of 4");
+  M3_REQUIRE(hist && chunk_len && step, "attention (stream): null state");
+  const int QT = cdiv(C, 16);
+  dim3 grid(QT * H * B);
+  const int D = H * dk;
+#define M3_ATT_CASE(DK_)                                                                                            \
+  hipLaunchKernelGGL((relpos_attention_stream_kernel<DK_>), grid, dim3(256), 0, stream, qkv, ldq, hist, cap, pmat, ldp, \
+                     pos_u, pos_v, chunk_len, step, C, D, scale, out, ldo, QT, H, left_chunks)
+  switch (dk) {
+    case 16: M3_ATT_CASE(16); break;
+    case 32: M3_ATT_CASE(32); break;
+    case 64: M3_ATT_CASE(64); break;
+    case 128: M3_ATT_CASE(128); break;
+    default: M3_REQUIRE(false, "attention (stream): d_k=%d unsupported (16/32/64/128)", dk);
+  }
+#undef M3_ATT_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
 // The same operator on bf16 rows for the 16-bit modes of long batches (qkv written as bf16 by the QKV GEMM, context
 // written as bf16 for the output projection), T' <= 128 keys:  v_mfma_f32_16x16x32_bf16, fp32 softmax.
 //

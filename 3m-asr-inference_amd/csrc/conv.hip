@@ -17,6 +17,23 @@ namespace m3 {
 // channels per thread (D/4 threads): all K taps (z rows t-pad..t+pad and their weights) are loaded
 // before the first FMA, so a frame costs one memory round trip; edge taps read a clamped row and are
 // multiplied by 0 (= the conv's zero padding).  LayerNorm statistics go through a small LDS tree.
+//
+// Causal form (convolution.py:43-49,118-123: lorder = K - 1 frames are padded on the LEFT of the module's input, in front of
+// pointwise_conv1, and the depthwise conv runs without padding): out[t] = sum_k w[k] z[t - (K-1) + k], no taps to the right.
+// The K-1 frames left of frame 0 are not zeros at the depthwise conv's input: pointwise_conv1 + GLU turn a zero frame into
+// the constant row GLU(bias).  `cs.left` supplies them: one broadcast row ("left_fill" of the plan; full-utterance forward),
+// or, chunk by chunk, the last K-1 frames of the previous chunk's z from the streaming state (a ping-pong pair selected by
+// the parity of the device-side chunk counter; the work-groups past the B*T frames write the other half: the new cache =
+// the last K-1 frames of [cache | z[0 : len)], cat_split_cache_kernel.cu:30-55's contract on frames instead of elements).
+struct DwCausal {
+  int causal = 0;                          // 1: lorder = K - 1, no right taps
+  const float* left = nullptr;             // causal: frames t < 0.  left_t_stride 0: one row [D] for every t < 0 and utterance
+  long left_b_stride = 0; int left_t_stride = 0;
+  const int32_t* step = nullptr;           // streaming: device-side chunk counter; `left` then is the [2][B][K-1][D] ping-pong pair
+  long half = 0;                           // floats in one half of the pair
+  const int32_t* chunk_len = nullptr;      // streaming: valid frames of this chunk per utterance
+};
+
 template <int KT>
 __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
                                                               const float* __restrict__ bias,
@@ -25,12 +42,29 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
                                                               int D, int K, float* __restrict__ out, int out_bf16,
                                                               const int32_t* __restrict__ pad_of,
                                                               const int32_t* __restrict__ row0,
-                                                              const int32_t* __restrict__ row_len) {
+                                                              const int32_t* __restrict__ row_len, int n_rows, DwCausal cs) {
   __shared__ float red[2][16];
   // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~6 dependent s_load rounds otherwise)
   asm volatile("" ::"s"(z), "s"(w_kc), "s"(bias), "s"(gamma), "s"(beta), "s"(eps), "s"(T), "s"(D), "s"(K), "s"(out), "s"(out_bf16),
-               "s"(pad_of), "s"(row0), "s"(row_len));
+               "s"(pad_of), "s"(row0), "s"(row_len), "s"(n_rows), "s"(cs.causal), "s"(cs.left), "s"(cs.left_b_stride),
+               "s"(cs.left_t_stride), "s"(cs.step), "s"(cs.half), "s"(cs.chunk_len));
   const int row = blockIdx.x;
+  const int c = threadIdx.x * 4;
+  const bool live = c < D;
+  const float* leftp = cs.left;
+  if (cs.step != nullptr) {                         // streaming: read half (step & 1), write the other one
+    const int par = *cs.step & 1;
+    leftp = cs.left + (size_t)par * cs.half;
+    if (row >= n_rows) {                            // cache update: row i of utterance b <- frame i + len of [cache | z]
+      const int i = row - n_rows, b = i / (K - 1), ci = i - b * (K - 1);
+      const int s = ci + min(max(cs.chunk_len[b], 0), T);
+      const float* src = s < K - 1 ? leftp + (size_t)b * cs.left_b_stride + (size_t)s * cs.left_t_stride
+                                   : z + ((size_t)b * T + (s - (K - 1))) * D;
+      float* dst = const_cast<float*>(cs.left) + (size_t)(par ^ 1) * cs.half + (size_t)b * cs.left_b_stride + (size_t)ci * cs.left_t_stride;
+      if (live) stg4(dst + c, ldg4(src + c));
+      return;
+    }
+  }
   // padded rows: row = b T + t.  Packed rows (pad_of != null): row p is frame pad_of[p] = b T + t of the padded layout
   // (-1 past the last packed row P); utterance b owns rows [row0[b], row0[b] + len).  The reference runs the conv on the
   // padded batch, where the frames len <= tt < T hold the constant row pointwise_conv1 produces from a zeroed input
@@ -45,11 +79,10 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
     t = pr - b * T;
     len = row_len[b];
     r0 = (size_t)row0[b];
-    rpad = (size_t)row0[gridDim.x / T];               // P = row0[B]
+    rpad = (size_t)row0[n_rows / T];                  // P = row0[B]
   }
-  const int pad = (K - 1) / 2;
-  const int c = threadIdx.x * 4;
-  const bool live = c < D;
+  const int pad = cs.causal ? K - 1 : (K - 1) / 2;
+  if (cs.causal) leftp += (size_t)b * cs.left_b_stride + (size_t)(K - 1) * cs.left_t_stride;   // frame tt < 0 is leftp + tt * left_t_stride
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
   if (live) {
@@ -61,9 +94,15 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
       for (int kk = 0; kk < KT; ++kk) {
         const int k = min(k0 + kk, K - 1);
         const int tt = t + k - pad;
-        on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
         const int tc = min(max(tt, 0), T - 1);
-        zz[kk] = ldg4(z + (tc < len ? r0 + tc : rpad) * D + c);
+        const float* src = z + (tc < len ? r0 + tc : rpad) * D;
+        if (cs.causal) {                              // no taps to the right; frames left of the utterance come from `left`
+          on[kk] = (k0 + kk < K) ? 1.f : 0.f;
+          if (tt < 0) src = leftp + (long)tt * cs.left_t_stride;
+        } else {
+          on[kk] = (k0 + kk < K && tt >= 0 && tt < T) ? 1.f : 0.f;
+        }
+        zz[kk] = ldg4(src + c);
         ww[kk] = ldg4(w_kc + (size_t)k * D + c);
       }
 #pragma unroll
@@ -114,22 +153,43 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
   }
 }
 
-int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
-                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16,
-                          const int32_t* pad_of, const int32_t* row0, const int32_t* row_len) {
+static int launch_dwconv_impl(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta, float eps,
+                              int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16, const int32_t* pad_of,
+                              const int32_t* row0, const int32_t* row_len, const DwCausal& cs) {
   M3_REQUIRE((D & 3) == 0 && D <= 4096, "dwconv: channels=%d must be a multiple of 4 (<=4096)", D);
-  M3_REQUIRE((K & 1) == 1, "dwconv: kernel size %d must be odd (non-causal)", K);
+  M3_REQUIRE(cs.causal || (K & 1) == 1, "dwconv: kernel size %d must be odd (non-causal)", K);
+  M3_REQUIRE(!cs.causal || (cs.left != nullptr && K >= 2), "dwconv (causal): the frames left of frame 0 must be supplied (left_fill / cache)");
   const int rows = B * T;
   if (rows == 0) return 0;
   const int threads = (int)align_up(D / 4, 64);
+  const int grid = rows + (cs.step != nullptr ? B * (K - 1) : 0);     // streaming: + the work-groups that write the new cache
   if (K <= 15)
-    hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len);
+    hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(grid), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
+                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len, rows, cs);
   else
-    hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(rows), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len);
+    hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(grid), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
+                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len, rows, cs);
   M3_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
+                          const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16,
+                          const int32_t* pad_of, const int32_t* row0, const int32_t* row_len, const float* causal_left_fill) {
+  DwCausal cs;
+  if (causal_left_fill != nullptr) { cs.causal = 1; cs.left = causal_left_fill; }
+  return launch_dwconv_impl(z, w_kc, bias, gamma, beta, eps, B, T, D, K, out, stream, out_bf16, pad_of, row0, row_len, cs);
+}
+
+// chunk-by-chunk (streaming) form of the causal conv: cache_pair [2][B][K-1][D], chunk counter and valid frames on the device
+int launch_dwconv_ln_silu_stream(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
+                                 float eps, int B, int T, int D, int K, float* out, float* cache_pair, const int32_t* step,
+                                 const int32_t* chunk_len, hipStream_t stream, int out_bf16) {
+  M3_REQUIRE(cache_pair && step && chunk_len, "dwconv (stream): null state");
+  DwCausal cs;
+  cs.causal = 1; cs.left = cache_pair; cs.left_b_stride = (long)(K - 1) * D; cs.left_t_stride = D;
+  cs.step = step; cs.half = (long)B * (K - 1) * D; cs.chunk_len = chunk_len;
+  return launch_dwconv_impl(z, w_kc, bias, gamma, beta, eps, B, T, D, K, out, stream, out_bf16, nullptr, nullptr, nullptr, cs);
 }
 
 // feat [B][T][idim] -> out [B][T1][F1][C] (channel-last), w9c [9][C] (repacked from (C,1,3,3)), ReLU.

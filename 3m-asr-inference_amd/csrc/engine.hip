@@ -43,6 +43,7 @@ struct BlockW {
   Lin mac1, mac2, qkv, pos, out, pw1, pw2, ff1, ff2;
   const float* pos_u = nullptr; const float* pos_v = nullptr;
   const float* dw_w = nullptr; const float* dw_b = nullptr;
+  const float* left_fill = nullptr;   // causal conv module: GLU(pointwise_conv1.bias), what a zero-padded frame is at the depthwise conv's input
   Lin router;                       // w: [E_total][D + De]  (unfused route path)
   Lin router_x;                     // w: [E][D] x-half with norm_ff folded (+ wsum, bias)  (fused route path)
   const float *ew1 = nullptr, *eb1 = nullptr, *ew2 = nullptr, *eb2 = nullptr;
@@ -98,6 +99,9 @@ struct m3_engine {
     bool lens_in_conv1 = false;
     const float *tail_ln_g = nullptr, *tail_ln_b = nullptr; float tail_ln_eps = 0.f; float* tail_ln_out = nullptr;
     int ep_cap = 0;        // expert parallel: rows per wire chunk this binding was built for (m3_engine_set_ep_capacity)
+    // chunk-by-chunk (streaming) binding: T = 4 c + 3 input frames -> the c frames of one chunk; attention reads / extends the
+    // K / V history and the causal depthwise conv its K-1 frame cache, both in the caller-owned state (m3_engine_forward_chunk)
+    void* sstate = nullptr; int s_hist = 0, s_maxf = 0;
     // fork_embed: stages [fork_first, fork_mid) = the embed encoder (side branch of the captured graph), [fork_mid, join_at) =
     // what the main encoder does before it needs the embedding; -1 = one linear chain
     int fork_first = -1, fork_mid = -1, join_at = -1;
@@ -111,9 +115,10 @@ struct m3_engine {
     hipGraphExec_t graph_exec = nullptr;
     bool graph_valid = false;
     uint64_t last_use = 0;
-    bool matches(int b, int t, const float* f, const int32_t* fl, const float* lg, const void* w, size_t wb, int cap) const {
+    bool matches(int b, int t, const float* f, const int32_t* fl, const float* lg, const void* w, size_t wb, int cap,
+                 const void* st = nullptr, int hist = 0, int maxf = 0) const {
       return !stages.empty() && B == b && T == t && feat == f && feat_len == fl && logits == lg && ws == w && ws_bytes == wb &&
-             ep_cap == cap;
+             ep_cap == cap && sstate == st && s_hist == hist && s_maxf == maxf;
     }
   };
   Bound cur;
@@ -189,7 +194,7 @@ bool load_lin_ln(const m3_engine* e, const std::string& p, int64_t n_out, int64_
   return true;
 }
 
-bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, bool cnn_ln, bool moe, int De, BlockW* b) {
+bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, bool cnn_ln, bool moe, int De, BlockW* b, bool causal) {
   const m3_engine_config& c = e->cfg;
   // norm_ff_macaron / norm_mha / norm_conv (and norm_ff of dense blocks) have no tensor of their own: folded into weights
   if (!load_norm(e, p + "norm_final.", D, &b->n_final)) return false;
@@ -206,6 +211,7 @@ bool load_block(const m3_engine* e, const std::string& p, int D, int F, int K, b
   GET(b->dw_w, p + "conv_module.depthwise_conv.weight_kc", (int64_t)K * D);
   GET(b->dw_b, p + "conv_module.depthwise_conv.bias", D);
   if (cnn_ln && !load_norm(e, p + "conv_module.norm.", D, &b->n_cnn)) return false;
+  if (causal) GET(b->left_fill, p + "conv_module.left_fill", D);
   if (!moe) {
     if (!load_lin_ln(e, p + "feed_forward.w_1.", F, D, false, &b->ff1) ||
         !load_lin(e, p + "feed_forward.w_2.", D, F, true, &b->ff2))
@@ -385,6 +391,26 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   return p;
 }
 
+// Layout of the caller-owned streaming state (identical code computes the size and the addresses): the device-side chunk
+// counter, then per block (embed blocks first) the K | V history [B][hist][2 D] and the depthwise conv's ping-pong cache
+// [2][B][K-1][D] (post-GLU frames; the reference caches the module's INPUT and re-runs pointwise_conv1 + GLU on it,
+// convolution.py:118-123 -- the same numbers, since both are per-frame operations).
+struct StreamState {
+  int32_t* step = nullptr;
+  std::vector<float*> kv, conv;
+  size_t bytes = 0;
+};
+StreamState carve_stream_state(const m3_engine_config& c, void* base, int B, int hist) {
+  Carver cv(base);
+  StreamState st;
+  st.step = cv.take<int32_t>(64);
+  const int nb = c.embed_blocks + c.num_blocks, D = c.attention_dim, K = c.cnn_module_kernel;
+  for (int i = 0; i < nb; ++i) st.kv.push_back(cv.take<float>((size_t)B * hist * 2 * D));
+  for (int i = 0; i < nb; ++i) st.conv.push_back(cv.take<float>((size_t)2 * B * (K - 1) * D));
+  st.bytes = cv.off;
+  return st;
+}
+
 // the same plan with the embed branch's scratch under the usual names (what the embed encoder's stages are built from)
 Plan embed_view(const Plan& pl) {
   Plan q = pl;
@@ -479,7 +505,7 @@ static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w,
 }
 
 static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, int D, int F, int H, int K, bool cnn_ln,
-                        bool moe, int layer, int tap_index, const Plan& pl) {
+                        bool moe, int layer, int tap_index, const Plan& pl, bool causal) {
   // every GEMM of a block is row-wise over the S rows of the batch: packed batches pass the live-row count
   auto add_gemm = [&](m3_engine* e_, const std::string& name, GemmParams g, bool fp32_weights = false) {
     if (e_->cur.packed) g.m_dev = pl.row0 + e_->cur.B;
@@ -545,6 +571,13 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int dk = D / H;
     const float scale = 1.f / sqrtf((float)dk);
     const int chunk = c.static_chunk_size, left_chunks = c.num_left_chunks;   // static chunk mask (0 = full context)
+    if (e->cur.sstate != nullptr) {   // chunk-by-chunk: keys = K / V history + this chunk, positions absolute, history appended in place
+      const StreamState st = carve_stream_state(c, e->cur.sstate, B, e->cur.s_hist);
+      float* hist = st.kv[tap_index]; const int cap = e->cur.s_hist; const int32_t* step = st.step;
+      add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
+        return launch_relpos_attention_stream(qkv, 3 * D, hist, cap, pmat, ldp, pu, pv, lens, step, B, Tp, H, dk, scale, ctx, D, left_chunks, s);
+      }, stage_info("relpos_attention_stream_kernel", 1, (double)S * D * 24 + (double)Tp * D * 4, 6.0 * Tp * D * S));
+    } else
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
       if (att16) return launch_relpos_attention_bf16(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, row0, chunk, left_chunks);
       return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0, chunk, left_chunks);
@@ -568,8 +601,16 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* glu = pl.glu; float* dw = pl.dw;
     const float* dww = w.dw_w; const float* dwb = w.dw_b;
     const float* ng = cnn_ln ? w.n_cnn.g : nullptr; const float* nb = cnn_ln ? w.n_cnn.b : nullptr;
+    const float* lfill = causal ? w.left_fill : nullptr;   // causal conv module (convolution.py:43-49,118-123)
+    if (e->cur.sstate != nullptr) {
+      const StreamState st = carve_stream_state(c, e->cur.sstate, B, e->cur.s_hist);
+      float* cpair = st.conv[tap_index]; const int32_t* step = st.step;
+      add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
+        return launch_dwconv_ln_silu_stream(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, cpair, step, lens, s, a16);
+      }, stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * 8 + (double)K * D * 4 + 8.0 * B * (K - 1) * D, 2.0 * K * D * S));
+    } else
     add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
-      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16, pad_of, row0, lens);
+      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16, pad_of, row0, lens, lfill);
     }, stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * (4 + (a16 ? 2 : 4)) + (double)K * D * 4, 2.0 * K * D * S));
     GemmParams h;
     h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
@@ -857,12 +898,12 @@ m3_engine* m3_engine_create(const m3_engine_config* config, const m3_weight_entr
   e->eblocks.resize(c.embed_blocks);
   for (int i = 0; i < c.embed_blocks; ++i)
     if (!load_block(e, "embed.blocks." + std::to_string(i) + ".", De, c.embed_linear_units, K, c.embed_cnn_layer_norm,
-                    false, De, &e->eblocks[i]))
+                    false, De, &e->eblocks[i], c.embed_causal > 0))
       return fail(nullptr);
   e->mblocks.resize(c.num_blocks);
   for (int i = 0; i < c.num_blocks; ++i)
     if (!load_block(e, "blocks." + std::to_string(i) + ".", D, c.hidden_units, K, c.cnn_layer_norm, true, De,
-                    &e->mblocks[i]))
+                    &e->mblocks[i], c.causal > 0))
       return fail(nullptr);
   return e;
 }
@@ -883,8 +924,8 @@ size_t m3_engine_workspace_size(const m3_engine* engine, int B, int T) {
   return make_plan(engine->cfg, nullptr, B, T, engine->ep_capacity).bytes;
 }
 
-int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
-                      void* workspace, size_t workspace_bytes) {
+static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                        void* workspace, size_t workspace_bytes, void* sstate, int s_hist, int s_maxf) {
   M3_REQUIRE(e && feat && feat_len && logits && workspace, "engine_prepare: null argument");
   M3_REQUIRE(B > 0 && T >= 7, "engine_prepare: need B > 0 and T >= 7 frames (got B=%d T=%d)", B, T);
   const m3_engine_config& c = e->cfg;
@@ -904,7 +945,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);
   M3_REQUIRE(workspace_bytes >= pl.bytes, "engine_prepare: workspace %zu bytes < required %zu", workspace_bytes, pl.bytes);
   // ---- shape cache: park the current binding, revive a parked one with the same (shape, buffers) ----
-  if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity)) {
+  if (e->cur.matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity, sstate, s_hist, s_maxf)) {
     e->cur.last_use = ++e->use_clock;
     return (int)e->cur.stages.size();
   }
@@ -925,7 +966,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     e->cur = m3_engine::Bound();
   }
   for (size_t i = 0; i < e->parked.size(); ++i)
-    if (e->parked[i].matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity)) {
+    if (e->parked[i].matches(B, T, feat, feat_len, logits, workspace, workspace_bytes, e->ep_capacity, sstate, s_hist, s_maxf)) {
       e->cur = std::move(e->parked[i]);
       e->parked.erase(e->parked.begin() + i);
       e->cur.last_use = ++e->use_clock;
@@ -935,6 +976,8 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.B = B; e->cur.T = T; e->cur.Tp = Tp; e->cur.S = B * Tp;
   e->cur.feat = feat; e->cur.feat_len = feat_len; e->cur.logits = logits; e->cur.ws = workspace; e->cur.ws_bytes = workspace_bytes;
   e->cur.ep_cap = e->ep_capacity;
+  e->cur.sstate = sstate; e->cur.s_hist = s_hist; e->cur.s_maxf = s_maxf;
+  const bool streaming = sstate != nullptr;
   e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false;
   e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
   {
@@ -951,6 +994,9 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
     e->cur.dma = e->cur.a16 && c.attention_dim == 128 * kXbStatParts && gemm_bf16w_uses_dma(t);
   }
   e->cur.packed = use_packed_rows(c, B);
+  if (streaming) {   // a chunk is a few rows per utterance: padded layout, fp32 activations (the 16-bit modes keep their bf16 weights)
+    e->cur.a16 = e->cur.dma = e->cur.packed = false;   // (the plan's packed-row buffers stay carved, unused)
+  }
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
   const int S = e->cur.S, D = c.attention_dim, De = c.embed_dim;
 
@@ -966,7 +1012,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
       int32_t* row0 = pl.row0; int32_t* pad_of = pl.pad_of;
       add_stage(e, "pack_plan", 1, [=](hipStream_t s) { return launch_pack_plan(lens, B, Tp, row0, pad_of, s, feat_len); },
                 stage_info("pack_plan_kernel", 1, 12.0 * B + 4.0 * B * Tp, 0.0, false));
-    } else if (pl.fork || !c.fold_pos_proj) {
+    } else if (pl.fork || (!c.fold_pos_proj && !streaming)) {
       add_stage(e, "lens", 1, [=](hipStream_t s) { return launch_subsample_lens(feat_len, B, lens, s); },
                 stage_info("subsample_lens_kernel", 1, 8.0 * B, 0.0, false));
     } else {
@@ -978,20 +1024,23 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   {
     const int nb = c.num_blocks + c.embed_blocks;
     GemmParams pp;
-    pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tp; pp.N = nb * D; pp.K = D;
-    if (c.fold_pos_proj) {
+    // (streaming: keys carry their ABSOLUTE position, rel_positional_encoding_kernel.cu:108-111 pe[offset : offset + T]: one
+    //  table over the s_maxf positions a stream can reach, always folded)
+    const int Tpos = streaming ? s_maxf : Tp;
+    pp.A = e->pe; pp.lda = D; pp.W = e->pos_all; pp.Y = pl.pbuf; pp.ldy = nb * D; pp.M = Tpos; pp.N = nb * D; pp.K = D;
+    if (c.fold_pos_proj || streaming) {
       for (auto it = e->pfold_by_tp.begin(); it != e->pfold_by_tp.end();)      // tables no binding holds any more
         it = it->second.expired() ? e->pfold_by_tp.erase(it) : std::next(it);
-      std::shared_ptr<float> pf = e->pfold_by_tp.count(Tp) ? e->pfold_by_tp[Tp].lock() : nullptr;
+      std::shared_ptr<float> pf = e->pfold_by_tp.count(Tpos) ? e->pfold_by_tp[Tpos].lock() : nullptr;
       if (!pf) {
         float* dev = nullptr;
-        M3_CHECK_HIP(hipMalloc((void**)&dev, (size_t)Tp * nb * D * sizeof(float)));
+        M3_CHECK_HIP(hipMalloc((void**)&dev, (size_t)Tpos * nb * D * sizeof(float)));
         pf = std::shared_ptr<float>(dev, [](float* q) { (void)hipFree(q); });
         pp.Y = dev;
         pp.w_bf16 = c.weight_dtype != M3_F32;
         if (int rc = launch_gemm_f32(pp, nullptr)) return rc;
         M3_CHECK_HIP(hipStreamSynchronize(nullptr));
-        e->pfold_by_tp[Tp] = pf;
+        e->pfold_by_tp[Tpos] = pf;
       }
       e->cur.pfold = pf;
       pl.pbuf = pf.get();
@@ -1009,7 +1058,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
       e->cur.tail_ln_g = e->e_after.g; e->cur.tail_ln_b = e->e_after.b; e->cur.tail_ln_eps = 1e-12f; e->cur.tail_ln_out = pl.emb;
     }
     build_block(e, "embed.blocks." + std::to_string(i) + ".", e->eblocks[i], De, c.embed_linear_units, c.embed_heads,
-                c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, ple);
+                c.cnn_module_kernel, c.embed_cnn_layer_norm, false, i, i, ple, c.embed_causal > 0);
   }
   e->cur.splitk_ws = pl.splitk;
   if (c.embed_blocks == 0) {
@@ -1032,7 +1081,7 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);
   for (int i = 0; i < c.num_blocks; ++i)
     build_block(e, "blocks." + std::to_string(i) + ".", e->mblocks[i], D, c.hidden_units, c.attention_heads,
-                c.cnn_module_kernel, c.cnn_layer_norm, true, i, c.embed_blocks + i, pl);
+                c.cnn_module_kernel, c.cnn_layer_norm, true, i, c.embed_blocks + i, pl, c.causal > 0);
   {
     GemmParams g;
     g.A = pl.x; g.lda = D; g.W = e->out_linear.w; g.bias = e->out_linear.b; g.Y = logits; g.ldy = c.output_dim;
@@ -1067,6 +1116,11 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
       }
     if (e->cur.join_at < 0 || c.num_blocks < 1) e->cur.fork_first = e->cur.fork_mid = e->cur.join_at = -1;
   }
+  if (streaming) {   // the chunk counter moves on the device: the same captured graph serves every chunk of the stream
+    int32_t* step = carve_stream_state(c, sstate, B, s_hist).step;
+    add_stage(e, "stream.advance", 1, [=](hipStream_t s) { return launch_advance_counter(step, 1, s); },
+              stage_info("advance_counter_kernel", 1, 8.0, 0.0, false));
+  }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
   e->cur.buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
@@ -1077,6 +1131,11 @@ int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, 
   e->cur.buffers["router_logits"] = Buf{pl.rl, (size_t)S * c.num_experts * (c.ep_world_size > 0 ? c.ep_world_size : 1) * 4};
 
   return (int)e->cur.stages.size();
+}
+
+int m3_engine_prepare(m3_engine* e, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
+                      void* workspace, size_t workspace_bytes) {
+  return prepare_impl(e, feat, feat_len, B, T, logits, workspace, workspace_bytes, nullptr, 0, 0);
 }
 
 int m3_engine_set_ep_capacity(m3_engine* engine, int rows_per_chunk) {
@@ -1166,6 +1225,91 @@ int m3_engine_forward(m3_engine* e, const float* feat, const int32_t* feat_len, 
       if (graph) (void)hipGraphDestroy(graph);
       return rc;
     }
+    M3_CHECK_HIP(ce);
+    M3_CHECK_HIP(hipGraphInstantiate(&e->cur.graph_exec, graph, nullptr, nullptr, 0));
+    M3_CHECK_HIP(hipGraphDestroy(graph));
+    e->cur.graph_valid = true;
+    ++e->n_captures;
+  }
+  M3_CHECK_HIP(hipGraphLaunch(e->cur.graph_exec, stream));
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Chunk-by-chunk (streaming) execution: decoding-chunk semantics of trainer_3m_fix/model/encoder.py:100-140
+// (decoding_chunk_size / num_decoding_left_chunks -> add_optional_chunk_mask) with the caches the reference's streaming plugins
+// were written for (cat_split_cache_kernel.cu:30-107, att_stream_softmax_kernel.cu:136-191,
+// rel_positional_encoding_kernel.cu:108-123).  Contract: with static_chunk_size = c, causal conv modules in both encoders and
+// the same weights, the logits of chunk n equal rows [n c, (n + 1) c) of the full-utterance forward (m3_engine_forward) up to
+// fp32 rounding of the GEMMs (their kernels are chosen by row count); the attention core and the conv are bit-exact.
+static int stream_check(const m3_engine* e, const m3_stream_desc* d) {
+  M3_REQUIRE(e != nullptr && d != nullptr, "engine stream: null argument");
+  const m3_engine_config& c = e->cfg;
+  M3_REQUIRE(c.static_chunk_size > 0, "engine stream: the engine was built without static_chunk_size (the chunk length in output frames)");
+  M3_REQUIRE(c.causal > 0 && c.embed_causal > 0, "engine stream: both encoders need causal conv modules (a symmetric depthwise conv "
+             "looks %d frames into the future)", (int)(c.cnn_module_kernel - 1) / 2);
+  M3_REQUIRE(c.ep_world_size <= 1 && c.ep_stages <= 0 && c.fork_embed <= 0, "engine stream: expert-parallel stages / forked capture are not available chunk by chunk");
+  M3_REQUIRE(d->B > 0 && d->max_frames >= c.static_chunk_size && d->max_frames < e->pe_rows,
+             "engine stream: need B > 0 and chunk <= max_frames < %lld positions (got B=%d max_frames=%d)", (long long)e->pe_rows, d->B, d->max_frames);
+  const int need = c.num_left_chunks < 0 ? d->max_frames : (c.num_left_chunks + 1) * c.static_chunk_size;
+  M3_REQUIRE(d->history_frames >= need, "engine stream: history_frames=%d < %d (%s)", d->history_frames, need,
+             c.num_left_chunks < 0 ? "all left chunks are visible: the history must hold the whole stream" : "(num_left_chunks + 1) chunks");
+  return 0;
+}
+
+int m3_engine_chunk_input_frames(const m3_engine* engine) {
+  // c output frames need input frames [4 j0, 4 (j0 + c - 1) + 6]: 4 c + 3 of them, advancing by 4 c per chunk (7-frame context of
+  // the two stride-2 3x3 convs, subsampling.py:103-145)
+  return engine && engine->cfg.static_chunk_size > 0 ? 4 * engine->cfg.static_chunk_size + 3 : 0;
+}
+
+size_t m3_engine_stream_state_size(const m3_engine* engine, const m3_stream_desc* desc) {
+  if (stream_check(engine, desc)) return 0;
+  return carve_stream_state(engine->cfg, nullptr, desc->B, desc->history_frames).bytes;
+}
+
+int m3_engine_stream_reset(m3_engine* e, const m3_stream_desc* desc, void* state, size_t state_bytes, m3_stream stream_) {
+  if (int rc = stream_check(e, desc)) return rc;
+  const m3_engine_config& c = e->cfg;
+  const StreamState st = carve_stream_state(c, state, desc->B, desc->history_frames);
+  M3_REQUIRE(state != nullptr && state_bytes >= st.bytes, "engine_stream_reset: state %zu bytes < required %zu", state_bytes, st.bytes);
+  hipStream_t stream = (hipStream_t)stream_;
+  M3_CHECK_HIP(hipMemsetAsync(st.step, 0, 64 * sizeof(int32_t), stream));
+  // the K-1 frames left of frame 0 are what the conv module's zero padding becomes behind pointwise_conv1 + GLU
+  const int K = c.cnn_module_kernel, D = c.attention_dim, nb = c.embed_blocks + c.num_blocks;
+  for (int i = 0; i < nb; ++i) {
+    const BlockW& w = i < c.embed_blocks ? e->eblocks[i] : e->mblocks[i - c.embed_blocks];
+    if (int rc = launch_fill_rows(w.left_fill, D, st.conv[i], (size_t)2 * desc->B * (K - 1), stream)) return rc;
+  }
+  return 0;
+}
+
+int m3_engine_forward_chunk(m3_engine* e, const m3_stream_desc* desc, void* state, size_t state_bytes, const float* feat_chunk,
+                            const int32_t* chunk_feat_len, float* logits, void* workspace, size_t workspace_bytes, int chunk_index,
+                            int use_graph, m3_stream stream_) {
+  if (int rc = stream_check(e, desc)) return rc;
+  const m3_engine_config& c = e->cfg;
+  const int C = c.static_chunk_size, T = 4 * C + 3, B = desc->B;
+  const size_t need = carve_stream_state(c, nullptr, B, desc->history_frames).bytes;
+  M3_REQUIRE(state != nullptr && state_bytes >= need, "engine_forward_chunk: state %zu bytes < required %zu", state_bytes, need);
+  M3_REQUIRE(chunk_index >= 0 && (long)(chunk_index + 1) * C <= desc->max_frames,
+             "engine_forward_chunk: chunk %d ends past max_frames=%d (the stream is longer than the state was sized for)", chunk_index, desc->max_frames);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!e->cur.matches(B, T, feat_chunk, chunk_feat_len, logits, workspace, workspace_bytes, e->ep_capacity, state, desc->history_frames, desc->max_frames)) {
+    int rc = prepare_impl(e, feat_chunk, chunk_feat_len, B, T, logits, workspace, workspace_bytes, state, desc->history_frames, desc->max_frames);
+    if (rc < 0) return rc;
+  }
+  e->cur.last_use = ++e->use_clock;
+  if (!use_graph) return m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
+  if (!e->cur.graph_valid) {
+    M3_REQUIRE(stream != nullptr, "engine_forward_chunk: graph capture needs a non-default stream");
+    if (e->cur.graph_exec) { (void)hipGraphExecDestroy(e->cur.graph_exec); e->cur.graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    M3_CHECK_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int rc = m3_engine_run(e, 0, (int)e->cur.stages.size(), stream_);
+    hipError_t ce = hipStreamEndCapture(stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     M3_CHECK_HIP(ce);
     M3_CHECK_HIP(hipGraphInstantiate(&e->cur.graph_exec, graph, nullptr, nullptr, 0));
     M3_CHECK_HIP(hipGraphDestroy(graph));

@@ -193,6 +193,10 @@ int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ld
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
                             float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr,
                             int chunk = 0, int left_chunks = -1);   // chunk > 0: static chunk mask (utils/mask.py:42-75)
+// chunk-by-chunk form: C query frames per utterance, K / V history [B][cap][2D] appended to in place, device-side chunk counter
+int launch_relpos_attention_stream(const float* qkv, int ldq, float* hist, int cap, const float* pmat, int ldp, const float* pos_u,
+                                   const float* pos_v, const int32_t* chunk_len, const int32_t* step, int B, int C, int H, int dk,
+                                   float scale, float* out, int ldo, int left_chunks, hipStream_t stream);
 
 // the same on bf16 rows (16-bit modes, T' <= 128): qkv bf16 [B*T][ldq], out bf16; one work-group per (utterance, head)
 bool relpos_attention_bf16_supports(int T, int dk);
@@ -205,7 +209,12 @@ int launch_relpos_attention_bf16(const void* qkv, int ldq, const float* pmat, in
 int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, const float* gamma,
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream,
                           int out_bf16 = 0, const int32_t* pad_of = nullptr, const int32_t* row0 = nullptr,
-                          const int32_t* row_len = nullptr);
+                          const int32_t* row_len = nullptr, const float* causal_left_fill = nullptr);   // non-null: causal conv (lorder K-1)
+int launch_advance_counter(int32_t* counter, int by, hipStream_t stream);
+int launch_fill_rows(const float* row, int D, float* out, size_t rows, hipStream_t stream);
+int launch_dwconv_ln_silu_stream(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
+                                 float eps, int B, int T, int D, int K, float* out, float* cache_pair, const int32_t* step,
+                                 const int32_t* chunk_len, hipStream_t stream, int out_bf16 = 0);
 // packed (padding-free) rows of a ragged batch (rowops.hip): plan from the valid lengths; padded output from packed rows
 int launch_pack_plan(int32_t* len, int B, int T, int32_t* row0, int32_t* pad_of, hipStream_t stream,
                      const int32_t* feat_len = nullptr);   // feat_len: form the subsampled lengths here too (len becomes an output)

@@ -490,6 +490,27 @@ int launch_mask_conv2d_sample(const int32_t* len_in, int B, int left_padding, in
   return 0;
 }
 
+// streaming state helpers (engine.hip, m3_engine_forward_chunk): the device-side chunk counter and the initial conv cache
+__global__ void advance_counter_kernel(int32_t* __restrict__ counter, int by) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *counter += by;
+}
+int launch_advance_counter(int32_t* counter, int by, hipStream_t stream) {
+  hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(64), 0, stream, counter, by);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void fill_rows_kernel(const float* __restrict__ row, int D, float* __restrict__ out, size_t rows) {
+  const size_t r = blockIdx.x;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) stg4(out + r * D + c, ldg4(row + c));
+}
+int launch_fill_rows(const float* row, int D, float* out, size_t rows, hipStream_t stream) {
+  M3_REQUIRE(row && out && (D & 3) == 0, "fill_rows: null pointer or D %% 4 != 0");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)rows), dim3(128), 0, stream, row, D, out, rows);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
 // both MaskConv2dSample applications of Conv2dSubsampling4 in one launch (subsampling.py:119-137)
 __global__ void subsample_lens_kernel(const int32_t* __restrict__ in, int B, int32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

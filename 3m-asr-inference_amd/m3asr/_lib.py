@@ -46,7 +46,11 @@ class EngineConfig(C.Structure):  # m3_engine_config
         "embed_dim", "embed_heads", "embed_linear_units", "embed_blocks",
         "num_experts", "hidden_units", "cnn_module_kernel", "cnn_layer_norm", "embed_cnn_layer_norm",
         "router_with_bias", "keep_expert_output", "ep_world_size", "ep_rank", "fold_pos_proj", "debug_taps", "log_softmax_out", "fuse_route",
-        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages", "fork_embed", "static_chunk_size", "num_left_chunks")]
+        "shape_cache", "bf16_activations", "weight_dtype", "packed_rows", "fp8_activations", "ep_stages", "fork_embed", "static_chunk_size", "num_left_chunks", "causal", "embed_causal")]
+
+
+class StreamDesc(C.Structure):  # m3_stream_desc
+    _fields_ = [("B", C.c_int32), ("history_frames", C.c_int32), ("max_frames", C.c_int32)]
 
 
 class WeightEntry(C.Structure):  # m3_weight_entry
@@ -142,6 +146,10 @@ SIGNATURES = {
     "m3_engine_workspace_size": (_sz, [_vp, _i, _i]),
     "m3_engine_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "m3_engine_prepare": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz]),
+    "m3_engine_chunk_input_frames": (_i, [_vp]),
+    "m3_engine_stream_state_size": (_sz, [_vp, _P(StreamDesc)]),
+    "m3_engine_stream_reset": (_i, [_vp, _P(StreamDesc), _vp, _sz, _vp]),
+    "m3_engine_forward_chunk": (_i, [_vp, _P(StreamDesc), _vp, _sz, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "m3_engine_set_ep_capacity": (_i, [_vp, _i]),
     "m3_engine_num_captures": (_i, [_vp]),
     "m3_engine_num_stages": (_i, [_vp]),

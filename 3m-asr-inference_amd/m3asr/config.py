@@ -47,6 +47,12 @@ class EncoderConfig:
     # of num_decoding_left_chunks chunks to the left (< 0: all of them) -- besides the padding mask.  0 = full context.
     static_chunk_size: int = 0
     num_decoding_left_chunks: int = -1
+    # causal ConvolutionModule (layer/convolution.py:43-49,118-123; constructor argument `causal` of the main encoder,
+    # ...domain_acc_hier.py:55,179, and embed_conf['causal'] of the embed encoder, conformer_embed_domain_acc.py:51,127):
+    # lorder = kernel - 1 frames padded on the left in front of pointwise_conv1, depthwise conv without padding.
+    # Together with static_chunk_size > 0 this is the configuration that can be decoded chunk by chunk (Engine.streaming).
+    causal: bool = False
+    embed_causal: bool = False
 
     def fp8_label(self):
         """What the fp8 mode of this config computes in (for reports: a weight-only mode must not read as fp8 MFMA)."""
@@ -103,6 +109,8 @@ class EncoderConfig:
             router_with_bias=moe.get("router_with_bias", False),
             keep_expert_output=moe.get("keep_expert_output", False),
             ep_world_size=moe.get("world_size", 1), ep_rank=moe.get("rank", 0),
+            static_chunk_size=ec.get("static_chunk_size", 0),
+            causal=bool(ec.get("causal", False)), embed_causal=bool(emb.get("causal", False)),
         )
 
 

@@ -42,6 +42,7 @@ def _engine_config(cfg: EncoderConfig, fold_pos_proj, debug_taps, fuse_route=Fal
     ec.fork_embed = 0 if fork_embed is None else (1 if fork_embed else -1)
     ec.static_chunk_size = int(getattr(cfg, "static_chunk_size", 0))
     ec.num_left_chunks = int(getattr(cfg, "num_decoding_left_chunks", -1))
+    ec.causal, ec.embed_causal = int(bool(getattr(cfg, "causal", False))), int(bool(getattr(cfg, "embed_causal", False)))
     return ec
 
 
@@ -193,6 +194,10 @@ class Engine:
         self.stream.synchronize()
         return out
 
+    def streaming(self, B, max_frames, history_frames=None):
+        """A set of B streams decoded chunk by chunk (see StreamingEncoder)."""
+        return StreamingEncoder(self, B, max_frames, history_frames)
+
     # ---- staged execution / taps ---------------------------------------------------------
     def stage_names(self):
         n = self.lib.m3_engine_num_stages(self.handle)
@@ -240,11 +245,100 @@ class Engine:
             out[b, :n] = rows[row0[b]:row0[b + 1]]
         return out
 
-    def buffer(self, name, dtype=torch.float32):
-        """Zero-copy view of a named intermediate inside the bound workspace."""
+    def buffer(self, name, dtype=torch.float32, ws=None):
+        """Zero-copy view of a named intermediate inside the bound workspace (ws: the workspace of the binding that ran last
+        when it is not this object's own, e.g. a StreamingEncoder's)."""
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         check(self.lib.m3_engine_buffer(self.handle, name.encode(), C.byref(ptr), C.byref(nbytes)), "m3_engine_buffer")
-        ws = self._bound[3]
+        ws = self._bound[3] if ws is None else ws
         off = ptr.value - ws.data_ptr()
         assert 0 <= off and off + nbytes.value <= ws.numel()
         return ws[off: off + nbytes.value].view(dtype)
+
+
+class StreamingEncoder:
+    """Chunk-by-chunk decoding of B utterances side by side (m3_engine_forward_chunk): the decoding-chunk semantics of the
+    reference's encoders (model/encoder.py:100-140: decoding_chunk_size, num_decoding_left_chunks) with per-layer K / V
+    history and depthwise-conv caches carried in device memory -- what the reference's CatSplitCache / AttStreamSoftmax /
+    streaming RelPositionalEncoding plugins were written for.  The engine's config must have static_chunk_size = c > 0 and
+    causal = embed_causal = True.
+
+        st = engine.streaming(B, max_frames)         # max_frames: longest stream in OUTPUT frames (T')
+        for n in range(n_chunks):
+            logits_chunk = st.step(window_n, valid_n)      # (B, c, V); window_n (B, 4c+3, idim), valid_n (B,) real frames in it
+
+    `decode(feat, feat_len)` cuts whole utterances into windows itself and returns (B, T', V) like Engine.__call__."""
+
+    def __init__(self, engine, B, max_frames, history_frames=None):
+        self.eng, cfg = engine, engine.cfg
+        self.c = int(cfg.static_chunk_size)
+        if self.c <= 0 or not (cfg.causal and cfg.embed_causal):
+            raise _lib.M3Error("StreamingEncoder needs static_chunk_size > 0 and causal conv modules in both encoders")
+        left = int(cfg.num_decoding_left_chunks)
+        max_frames = -(-int(max_frames) // self.c) * self.c                 # whole chunks
+        if history_frames is None:
+            history_frames = max_frames if left < 0 else (left + 1) * self.c
+        self.desc = _lib.StreamDesc(int(B), int(history_frames), int(max_frames))
+        self.window = engine.lib.m3_engine_chunk_input_frames(engine.handle)
+        n = engine.lib.m3_engine_stream_state_size(engine.handle, C.byref(self.desc))
+        if n == 0:
+            raise _lib.M3Error("m3_engine_stream_state_size failed: " + _lib.last_error())
+        dev = engine.device
+        self.state = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.feat = torch.zeros(B, self.window, cfg.input_dim, dtype=torch.float32, device=dev)
+        self.valid = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.logits = torch.empty(B, self.c, cfg.output_dim, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(engine.workspace_size(B, self.window), dtype=torch.uint8, device=dev)
+        self.chunks = 0
+        self.reset()
+
+    def reset(self):
+        e = self.eng
+        check(e.lib.m3_engine_stream_reset(e.handle, C.byref(self.desc), self.state.data_ptr(), self.state.numel(),
+                                           C.c_void_p(e.stream.cuda_stream)), "m3_engine_stream_reset")
+        self.chunks = 0
+
+    def step(self, window, valid, use_graph=True):
+        """One chunk: window (B, 4c+3, idim) feature frames starting at input frame 4 c n, valid (B,) how many of them are
+        real (pass 0 for an utterance with fewer than 7 frames left: no output frame fits).  Returns this object's logits
+        buffer (B, c, V), valid until the next step."""
+        e = self.eng
+        with torch.cuda.stream(e.stream):
+            self.feat.copy_(window, non_blocking=True)
+            self.valid.copy_(valid.to(torch.int32).reshape(-1), non_blocking=True)
+        check(e.lib.m3_engine_forward_chunk(e.handle, C.byref(self.desc), self.state.data_ptr(), self.state.numel(),
+                                            self.feat.data_ptr(), self.valid.data_ptr(), self.logits.data_ptr(),
+                                            self.ws.data_ptr(), self.ws.numel(), self.chunks, int(use_graph),
+                                            C.c_void_p(e.stream.cuda_stream)), "m3_engine_forward_chunk")
+        self.chunks += 1
+        return self.logits
+
+    def buffer(self, name, dtype=torch.float32):
+        """A named intermediate of the chunk that ran last (rows = B x c frames of that chunk)."""
+        return self.eng.buffer(name, dtype, ws=self.ws)
+
+    def decode(self, feat, feat_len, use_graph=True):
+        """Whole utterances through the chunked path: feat (B, T, idim), feat_len (B,) -> logits (B, T', V) (frames past an
+        utterance's end zeroed), the concatenation of the chunk outputs."""
+        e, c = self.eng, self.c
+        B, T = int(feat.shape[0]), int(feat.shape[1])
+        lens = feat_len.reshape(-1).to("cpu", torch.int64)
+        Tp = subsampled_len(T)
+        n_chunks = -(-Tp // c)
+        out = torch.zeros(B, n_chunks * c, e.cfg.output_dim, dtype=torch.float32, device=e.device)
+        self.reset()
+        e.stream.wait_stream(torch.cuda.current_stream())
+        feat = feat.to(e.device)
+        padded = torch.zeros(B, max(T, 4 * c * n_chunks + 3), feat.shape[2], dtype=torch.float32, device=e.device)
+        padded[:, :T] = feat
+        for n in range(n_chunks):
+            left = (lens - 4 * c * n).clamp(min=0, max=self.window)
+            left = torch.where(left >= 7, left, torch.zeros_like(left))
+            lg = self.step(padded[:, 4 * c * n: 4 * c * n + self.window], left, use_graph=use_graph)
+            with torch.cuda.stream(e.stream):
+                out[:, n * c:(n + 1) * c] = lg
+        e.stream.synchronize()
+        out = out[:, :Tp]
+        valid = torch.arange(Tp).view(1, -1) < torch.tensor([subsampled_len(int(v)) if v >= 7 else 0 for v in lens]).view(-1, 1)
+        out[~valid.to(out.device)] = 0
+        return out

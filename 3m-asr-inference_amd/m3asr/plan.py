@@ -110,6 +110,12 @@ def _pack_block(sd, p, out, norm, moe, cfg):
         db = (db - sd[c + "norm.running_mean"]) * s + sd[c + "norm.bias"]
     out[c + "depthwise_conv.weight_kc"] = dw.t().contiguous()
     out[c + "depthwise_conv.bias"] = db
+    if (cfg.causal if moe else cfg.embed_causal):
+        # causal module (convolution.py:43-49,118-123): lorder = K - 1 ZERO frames are padded in front of pointwise_conv1, so at
+        # the depthwise conv's input a frame left of the utterance is the constant GLU(pointwise_conv1.bias)
+        b1 = sd[c + "pointwise_conv1.bias"]
+        half = b1.numel() // 2
+        out[c + "left_fill"] = b1[:half] * torch.sigmoid(b1[half:])
     f = p + "feed_forward."
     if not moe:
         _put_folded(out, f + "w_1.", fold_layernorm(sd[f + "w_1.weight"], sd[f + "w_1.bias"],

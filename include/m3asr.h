@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 7
+#define M3ASR_ABI_VERSION 8
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -389,6 +389,10 @@ typedef struct m3_engine_config {
                                   * subsequent_chunk_mask :42-75): query frame i sees keys [max((i / c - left) c, 0),
                                   * min((i / c + 1) c, T')) and < len.  0 = full context */
   int32_t num_left_chunks;       /* chunks to the left a query sees with static_chunk_size > 0; < 0: all */
+  int32_t causal;                /* 1 = causal ConvolutionModule in the main encoder (convolution.py:43-49,118-123: lorder = K - 1
+                                  * frames padded on the left in front of pointwise_conv1, depthwise conv without padding); needs
+                                  * the plan entry "blocks.N.conv_module.left_fill" [D] = GLU(pointwise_conv1.bias) */
+  int32_t embed_causal;          /* the same for the embed encoder (conformer_embed_domain_acc.py:51,127; embed_conf['causal']) */
 } m3_engine_config;
 
 typedef struct m3_weight_entry {
@@ -415,6 +419,33 @@ int m3_engine_forward(m3_engine* engine, const float* feat, const int32_t* feat_
  * local index -> RCCL all-to-all -> m3_moe_expert_ffn on the received rows -> all-to-all back -> combine. */
 int m3_engine_prepare(m3_engine* engine, const float* feat, const int32_t* feat_len, int B, int T, float* logits,
                       void* workspace, size_t workspace_bytes);
+
+/* ---- chunk-by-chunk (streaming) execution -------------------------------------------------------------------------------
+ * Decoding-chunk semantics of trainer_3m_fix/model/encoder.py:100-140 (decoding_chunk_size, num_decoding_left_chunks) with
+ * the caches the reference's streaming plugins carry (cat_split_cache_kernel.cu:30-107, att_stream_softmax_kernel.cu:136-191,
+ * rel_positional_encoding_kernel.cu:108-123).  The engine must have static_chunk_size = c > 0 and causal = embed_causal = 1.
+ * B utterances are decoded side by side, one chunk of c output frames per call: the caller hands over the window of
+ * m3_engine_chunk_input_frames() = 4c + 3 feature frames that starts at input frame 4 c n (windows overlap by 3 frames, the
+ * context of the two stride-2 convs) and, per utterance, how many of its frames are real (0 for an utterance that has ended
+ * or has fewer than 7 frames left).  logits (B, c, V): rows past an utterance's valid frames are undefined.
+ * State (caller-owned device memory, m3_engine_stream_state_size bytes): a device-side chunk counter, per block the K | V
+ * history [B][history_frames][2D] (a ring when num_left_chunks >= 0: history_frames >= (num_left_chunks + 1) c; otherwise it
+ * must hold the whole stream) and the depthwise conv's K-1 frame cache.  max_frames bounds the stream's length in output
+ * frames (positions; < rows of "pe").  m3_engine_stream_reset starts a new set of B streams.  chunk_index is the host's
+ * count of chunks already decoded (validated against max_frames; the kernels use the device-side counter, so the call is a
+ * hipGraph replay from the second chunk on).  Contract: chunk n's logits equal rows [n c, (n+1) c) of m3_engine_forward on
+ * the whole utterances up to fp32 rounding of the GEMMs. */
+typedef struct m3_stream_desc {
+  int32_t B;
+  int32_t history_frames;
+  int32_t max_frames;
+} m3_stream_desc;
+int m3_engine_chunk_input_frames(const m3_engine* engine);
+size_t m3_engine_stream_state_size(const m3_engine* engine, const m3_stream_desc* desc);
+int m3_engine_stream_reset(m3_engine* engine, const m3_stream_desc* desc, void* state, size_t state_bytes, m3_stream stream);
+int m3_engine_forward_chunk(m3_engine* engine, const m3_stream_desc* desc, void* state, size_t state_bytes,
+                            const float* feat_chunk, const int32_t* chunk_feat_len, float* logits, void* workspace,
+                            size_t workspace_bytes, int chunk_index, int use_graph, m3_stream stream);
 /* Expert parallel: rows per wire chunk for the bindings made from now on (what the ranks agreed on: the largest row
  * count B*T' of any rank, so that a rank may send all of its rows to one peer; 0 = this rank's own row count).  The wire
  * buffers "ep.wire_a" / "ep.wire_b" ([world][1 + rows_per_chunk][D] fp32 each, inside the workspace) are what the host

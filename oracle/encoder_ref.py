@@ -135,18 +135,22 @@ def rel_pos_mha(x, pos_emb, lens, w, p, h, static_chunk_size=0, num_left_chunks=
     return F.linear(ctx, w[p + "linear_out.weight"], w[p + "linear_out.bias"])
 
 
-def conv_module(x, lens, w, p, kernel, norm):
+def conv_module(x, lens, w, p, kernel, norm, causal=False):
     """ConvolutionModule.forward (layer/convolution.py:83-167): transpose, masked_fill(0) on
     padded frames, pw-conv D->2D, GLU(dim=1), depthwise conv k (pad (k-1)/2), LayerNorm over
     channels (eps 1e-5, nn.LayerNorm default; or eval BatchNorm1d), SiLU, pw-conv D->D,
-    masked_fill(0), transpose back."""
+    masked_fill(0), transpose back.
+    causal (convolution.py:43-49): lorder = k - 1 zero frames are padded on the LEFT of the module's
+    input, in front of pointwise_conv1 (:118-123), and the depthwise conv has no padding of its own."""
     B, T, D = x.shape
     pad = torch.arange(T).view(1, 1, T) >= lens.view(B, 1, 1)
     z = x.transpose(1, 2).masked_fill(pad, 0.0)
+    if causal:
+        z = F.pad(z, (kernel - 1, 0), "constant", 0.0)
     z = F.conv1d(z, w[p + "pointwise_conv1.weight"], w[p + "pointwise_conv1.bias"])
     z = F.glu(z, dim=1)
     z = F.conv1d(z, w[p + "depthwise_conv.weight"], w[p + "depthwise_conv.bias"],
-                 padding=(kernel - 1) // 2, groups=D)
+                 padding=0 if causal else (kernel - 1) // 2, groups=D)
     if norm == "layer_norm":
         z = F.layer_norm(z.transpose(1, 2), (D,), w[p + "norm.weight"], w[p + "norm.bias"], 1e-5).transpose(1, 2)
     else:
@@ -257,7 +261,8 @@ def conformer_block(x, embed, lens, pos_emb, w, p, cfg, heads, kernel, norm, moe
                         getattr(cfg, "static_chunk_size", 0), getattr(cfg, "num_decoding_left_chunks", -1))
     if taps is not None:
         taps[tag + "after_mha"] = x
-    x = x + conv_module(layer_norm(x, w, p + "norm_conv.", eps), lens, w, p + "conv_module.", kernel, norm)
+    causal = bool(getattr(cfg, "causal" if moe else "embed_causal", False))
+    x = x + conv_module(layer_norm(x, w, p + "norm_conv.", eps), lens, w, p + "conv_module.", kernel, norm, causal)
     if taps is not None:
         taps[tag + "after_conv"] = x
     xn = layer_norm(x, w, p + "norm_ff.", eps)

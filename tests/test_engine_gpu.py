@@ -32,7 +32,7 @@ def _check(out, want, out_len):
     return float(err.max())
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid", "cfg2"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "cfg2", "causal", "causal_mid"])
 def test_engine_matches_golden(golden, name):
     cfg, z = golden(name)
     w = make_weights(cfg, seed=int(z["weight_seed"]))
