@@ -345,6 +345,10 @@ int m3_batched_matmul(const float* a, const float* b, float* c, int batch, int M
                       int64_t stride_b, int transpose_b, m3_stream stream) {
   return launch_bmm(a, b, c, batch, M, N, K, stride_a, stride_b, transpose_b, (hipStream_t)stream);
 }
+int m3_pad2d(const float* x, size_t outer, int H, int W, int pre_h, int post_h, int pre_w, int post_w, float* y, m3_stream stream) {
+  M3_REQUIRE(x && y, "pad2d: null pointer");
+  return launch_pad2d(x, outer, H, W, pre_h, post_h, pre_w, post_w, y, (hipStream_t)stream);
+}
 int m3_depthwise_conv1d(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad,
                         float* y, m3_stream stream) {
   return launch_depthwise_conv1d_nct(x, w, bias, B, C, T, K, pad, y, (hipStream_t)stream);

@@ -272,13 +272,16 @@ int launch_conv1_relu(const float* feat, const float* w9c, const float* bias, co
   return 0;
 }
 
+// y (B,C,To) = depthwise conv of x (B,C,T), To = T + 2 pad - K + 1 (nn.Conv1d: pad = (K-1)/2 keeps the length, the
+// causal module pads its input itself and convolves with pad = 0, convolution.py:43-49)
 __global__ void depthwise_conv1d_nct_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                            const float* __restrict__ bias, int C, int T, int K, int pad,
+                                            const float* __restrict__ bias, int C, int T, int To, int K, int pad,
                                             float* __restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i % T);
-    const int c = (int)((i / T) % C);
-    const float* xr = x + (i - t);
+    const int t = (int)(i % To);
+    const size_t bc = i / To;
+    const int c = (int)(bc % C);
+    const float* xr = x + bc * T;
     float acc = bias ? bias[c] : 0.f;
     for (int k = 0; k < K; ++k) {
       const int tt = t + k - pad;
@@ -290,10 +293,33 @@ __global__ void depthwise_conv1d_nct_kernel(const float* __restrict__ x, const f
 
 int launch_depthwise_conv1d_nct(const float* x, const float* w, const float* bias, int B, int C, int T, int K,
                                 int pad, float* y, hipStream_t stream) {
-  const size_t n = (size_t)B * C * T;
+  const int To = T + 2 * pad - K + 1;
+  M3_REQUIRE(pad >= 0 && To > 0, "depthwise_conv1d: T=%d K=%d pad=%d leaves no output", T, K, pad);
+  const size_t n = (size_t)B * C * To;
   if (n == 0) return 0;
   hipLaunchKernelGGL(depthwise_conv1d_nct_kernel, dim3(grid1d(n, 4096)), dim3(256), 0,
-                     stream, x, w, bias, C, T, K, pad, y, n);
+                     stream, x, w, bias, C, T, To, K, pad, y, n);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
+
+// zero padding of the last two dims: x (outer, H, W) -> y (outer, H + pre_h + post_h, W + pre_w + post_w)
+// (TensorRT IPaddingLayer, network.add_padding in the causal conv module, convolution.py:118-123)
+__global__ void pad2d_kernel(const float* __restrict__ x, int H, int W, int pre_h, int pre_w, int Ho, int Wo,
+                             float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
+    const size_t o = i / ((size_t)Wo * Ho);
+    const int h = ho - pre_h, w_ = wo - pre_w;
+    y[i] = (h >= 0 && h < H && w_ >= 0 && w_ < W) ? x[(o * H + h) * W + w_] : 0.f;
+  }
+}
+int launch_pad2d(const float* x, size_t outer, int H, int W, int pre_h, int post_h, int pre_w, int post_w, float* y, hipStream_t stream) {
+  M3_REQUIRE(pre_h >= 0 && post_h >= 0 && pre_w >= 0 && post_w >= 0, "pad2d: negative padding (cropping) is not implemented");
+  const int Ho = H + pre_h + post_h, Wo = W + pre_w + post_w;
+  const size_t n = outer * Ho * Wo;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(pad2d_kernel, dim3(grid1d(n, 4096)), dim3(256), 0, stream, x, H, W, pre_h, pre_w, Ho, Wo, y, n);
   M3_LAUNCH_CHECK();
   return 0;
 }

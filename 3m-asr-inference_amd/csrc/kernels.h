@@ -210,6 +210,7 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
                           const float* beta, float eps, int B, int T, int D, int K, float* out, hipStream_t stream,
                           int out_bf16 = 0, const int32_t* pad_of = nullptr, const int32_t* row0 = nullptr,
                           const int32_t* row_len = nullptr, const float* causal_left_fill = nullptr);   // non-null: causal conv (lorder K-1)
+int launch_pad2d(const float* x, size_t outer, int H, int W, int pre_h, int post_h, int pre_w, int post_w, float* y, hipStream_t stream);
 int launch_advance_counter(int32_t* counter, int by, hipStream_t stream);
 int launch_fill_rows(const float* row, int D, float* out, size_t rows, hipStream_t stream);
 int launch_dwconv_ln_silu_stream(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,

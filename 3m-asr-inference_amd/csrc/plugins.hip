@@ -27,12 +27,14 @@ int moe_expert_ffn(const float* x, const int32_t* gate_idx, const float* w1, con
 
 enum PluginKind {
   K_FMOE = 0, K_SOFTMAX_TOPK, K_ATT_MASKED_SOFTMAX, K_LAYER_NORM, K_MASKED_FILL, K_GLU, K_MASK_CONV2D_SAMPLE,
-  K_REL_POS_ENC, K_DUMP_TENSOR, K_COUNT
+  K_REL_POS_ENC, K_DUMP_TENSOR, K_CAT_SPLIT_CACHE, K_ATT_STREAM_SOFTMAX, K_COUNT
 };
 static const char* const kPluginNames[K_COUNT] = {
     "FMoEExpertPluginDynamic",      "SoftmaxTopKPluginDynamic", "AttMaskedSoftmaxPluginDynamic",
     "LayerNormPluginDynamic",       "MaskedFillPluginDynamic",  "GluPluginDynamic",
-    "MaskConv2dSamplePluginDynamic", "RelPositionalEncodingPluginDynamic", "DumpTensorPluginDynamic"};
+    "MaskConv2dSamplePluginDynamic", "RelPositionalEncodingPluginDynamic", "DumpTensorPluginDynamic",
+    // the streaming operators (built by the reference, cat_split_cache_plugin.h:26-27, att_stream_softmax_plugin.h:26-27)
+    "CatSplitCachePluginDynamic",   "AttStreamSoftmaxPluginDynamic"};
 
 // POD attribute block (what serialize() writes, reference: serialize.hpp:36-52)
 struct PluginAttrs {
@@ -46,6 +48,7 @@ struct PluginAttrs {
   int32_t axis_dim;                                  // Glu
   int32_t left_padding, stride;                      // MaskConv2dSample
   int32_t max_len, streaming;                        // RelPositionalEncoding
+  int32_t cache_len;                                 // AttStreamSoftmax (scale above; CatSplitCache uses axis_dim)
 };
 
 struct m3_plugin {
@@ -131,6 +134,12 @@ m3_plugin* m3_plugin_create(const char* plugin_name, const char* plugin_version,
       r.get_i32("streaming", &a.streaming);
       break;
     case K_DUMP_TENSOR: break;
+    case K_CAT_SPLIT_CACHE:      // cat_split_cache_plugin.cpp createPlugin: data_type, axis_dim
+      ok = has_dtype && r.get_i32("axis_dim", &a.axis_dim);
+      break;
+    case K_ATT_STREAM_SOFTMAX:   // att_stream_softmax_plugin.cpp createPlugin: data_type, scale, cache_len
+      ok = has_dtype && r.get_f32("scale", &a.scale) && r.get_i32("cache_len", &a.cache_len) && a.cache_len >= 0;
+      break;
   }
   if (!ok) {
     m3::set_error("plugin_create(%s): missing or invalid attribute", plugin_name);
@@ -155,13 +164,14 @@ void m3_plugin_destroy(m3_plugin* plugin) { delete plugin; }
 const char* m3_plugin_type(const m3_plugin* plugin) { return plugin ? kPluginNames[plugin->a.kind] : nullptr; }
 int m3_plugin_num_outputs(const m3_plugin* plugin) {
   if (!plugin) return 0;
-  return (plugin->a.kind == K_SOFTMAX_TOPK || plugin->a.kind == K_REL_POS_ENC) ? 2 : 1;
+  return (plugin->a.kind == K_SOFTMAX_TOPK || plugin->a.kind == K_REL_POS_ENC || plugin->a.kind == K_CAT_SPLIT_CACHE) ? 2 : 1;
 }
 
 static int expect_inputs(const m3_plugin* p, int n_in) {
-  static const int kNumInputs[K_COUNT] = {6, 2, 2, 3, 2, 1, 1, 2, 1};
-  M3_REQUIRE(n_in == kNumInputs[p->a.kind], "%s: expected %d inputs, got %d", kPluginNames[p->a.kind],
-             kNumInputs[p->a.kind], n_in);
+  static const int kNumInputs[K_COUNT] = {6, 2, 2, 3, 2, 1, 1, 2, 1, 2, 3};
+  // RelPositionalEncoding with streaming = 1 takes the frame counter as a third input (rel_positional_encoding_plugin.cpp:93-95)
+  const int want = kNumInputs[p->a.kind] + ((p->a.kind == K_REL_POS_ENC && p->a.streaming) ? 1 : 0);
+  M3_REQUIRE(n_in == want, "%s: expected %d inputs, got %d", kPluginNames[p->a.kind], want, n_in);
   return 0;
 }
 
@@ -193,6 +203,16 @@ int m3_plugin_output_dims(const m3_plugin* plugin, const m3_tensor* in, int n_in
       copy_shape(out[0], in[0]);
       copy_shape(out[1], in[1]); out[1].shape[1] = in[0].shape[1];
       break;
+    case K_CAT_SPLIT_CACHE: {  // inputs (cache, x): output = cat along axis_dim, out_cache like cache  (cat_split_cache_plugin.cpp:152-165)
+      const int ax = a.axis_dim < 0 ? in[1].ndim - 1 : a.axis_dim;
+      M3_REQUIRE(in[0].ndim == in[1].ndim && in[1].ndim >= 3 && ax > 0 && ax < in[1].ndim,
+                 "CatSplitCache: needs >= 3 dims and axis_dim in [1, ndim) (cat_split_cache_plugin.cpp:88-98), got ndim %d axis %d", in[1].ndim, a.axis_dim);
+      for (int i = 0; i < in[1].ndim; ++i)
+        M3_REQUIRE(i == ax || in[0].shape[i] == in[1].shape[i], "CatSplitCache: cache and input differ in dim %d", i);
+      copy_shape(out[0], in[1]); out[0].shape[ax] = in[0].shape[ax] + in[1].shape[ax];
+      copy_shape(out[1], in[0]);
+      break;
+    }
     default: copy_shape(out[0], in[0]); break;
   }
   return 0;
@@ -266,9 +286,31 @@ int m3_plugin_enqueue(m3_plugin* plugin, const m3_tensor* in, int n_in, m3_tenso
       M3_REQUIRE(in[0].shape[1] < a.max_len, "RelPositionalEncoding: T'=%lld must be < max_len=%d",
                  (long long)in[0].shape[1], a.max_len);  // rel_positional_encoding_plugin.cpp:139-142
       // one launch for both outputs (the reference's kernel does the same, rel_positional_encoding_kernel.cu:62-69)
-      return m3::launch_rel_positional_encoding((const float*)in[0].data, (const float*)in[1].data, (int)in[1].shape[1], nullptr, 0,
+      // streaming = 1: pos_emb = pe[off : off + T], off = frame_num[0] (the kernel's stated contract,
+      // rel_positional_encoding_kernel.cu:108-111); the offset is bounded by the table on the device side (max_offset)
+      const int32_t* frame_num = a.streaming ? (const int32_t*)in[2].data : nullptr;
+      if (a.streaming) M3_REQUIRE(in[2].dtype == M3_I32, "RelPositionalEncoding: frame_num must be int32");
+      const int pe_len = (int)in[1].shape[1];
+      return m3::launch_rel_positional_encoding((const float*)in[0].data, (const float*)in[1].data, pe_len, frame_num,
+                                                a.streaming ? pe_len - (int)in[0].shape[1] : 0,
                                                 a.scale, (int)in[0].shape[0], (int)in[0].shape[1], a.dim,
                                                 (float*)out[0].data, (float*)out[1].data, nullptr, stream);
+    }
+    case K_CAT_SPLIT_CACHE: {   // cat_split_cache_plugin.cpp:113-150: batch = prod(dims before axis), rows = the rest
+      const int ax = a.axis_dim < 0 ? in[1].ndim - 1 : a.axis_dim;
+      M3_REQUIRE(in[0].ndim == in[1].ndim && ax > 0 && ax < in[1].ndim, "CatSplitCache: bad axis_dim %d", a.axis_dim);
+      M3_REQUIRE(in[0].dtype == in[1].dtype && (in[1].dtype == M3_F32 || in[1].dtype == M3_I32), "CatSplitCache: 4-byte elements only");
+      int64_t batch = 1, input_dim = 1, cache_dim = 1;
+      for (int i = 0; i < ax; ++i) batch *= in[1].shape[i];
+      for (int i = ax; i < in[1].ndim; ++i) { input_dim *= in[1].shape[i]; cache_dim *= in[0].shape[i]; }
+      return m3::launch_cat_split_cache(in[0].data, in[1].data, (int)batch, (int)cache_dim, (int)input_dim, out[0].data, out[1].data, stream);
+    }
+    case K_ATT_STREAM_SOFTMAX: {   // att_stream_softmax_plugin.cpp:95-126: scores (B, h, T, ld), decode_frame_num [B], mask_idx [B]
+      M3_REQUIRE(in[0].ndim == 4, "AttStreamSoftmax: scores must be (B,h,T,ld)");
+      M3_REQUIRE(in[1].dtype == M3_I32 && in[2].dtype == M3_I32, "AttStreamSoftmax: decode_frame_num / mask_idx must be int32");
+      return m3::launch_att_stream_softmax((const float*)in[0].data, (const int32_t*)in[1].data, (const int32_t*)in[2].data,
+                                           (int)in[0].shape[0], (int)(in[0].shape[1] * in[0].shape[2]), (int)in[0].shape[3], a.cache_len,
+                                           a.scale, (float*)out[0].data, stream);
     }
     case K_DUMP_TENSOR: {
       size_t es = (in[0].dtype == M3_F16 || in[0].dtype == M3_BF16) ? 2 : (in[0].dtype == M3_I8 ? 1 : 4);

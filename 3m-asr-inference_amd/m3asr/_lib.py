@@ -139,6 +139,7 @@ SIGNATURES = {
     "m3_concat_last": (_i, [_vp, _i, _vp, _i, _vp, _sz, _vp]),
     "m3_softmax": (_i, [_vp, _vp, _sz, _i, _vp]),
     "m3_batched_matmul": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i, _vp]),
+    "m3_pad2d": (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "m3_depthwise_conv1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m3_engine_create": (_vp, [_P(EngineConfig), _P(WeightEntry), _i]),
     "m3_engine_destroy": (None, [_vp]),

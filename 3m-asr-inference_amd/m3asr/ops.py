@@ -530,7 +530,17 @@ def depthwise_conv1d(x, w, bias, pad):
     lib = _lib.load()
     B, Cc, T = x.shape
     K = w.shape[-1]
-    y = torch.empty_like(x)
+    y = torch.empty(B, Cc, T + 2 * int(pad) - K + 1, dtype=torch.float32, device=x.device)
     check(lib.m3_depthwise_conv1d(_f32(x), _f32(w.reshape(Cc, K)), _f32(bias), B, Cc, T, K, pad, _p(y), _stream()),
           "m3_depthwise_conv1d")
+    return y
+
+
+def pad2d(x, pre, post):
+    """TensorRT IPaddingLayer on the last two dims: pre = (h, w), post = (h, w) zeros."""
+    lib = _lib.load()
+    H, W = x.shape[-2], x.shape[-1]
+    outer = x.numel() // max(H * W, 1)
+    y = torch.empty(tuple(x.shape[:-2]) + (H + pre[0] + post[0], W + pre[1] + post[1]), dtype=torch.float32, device=x.device)
+    check(lib.m3_pad2d(_f32(x), outer, H, W, int(pre[0]), int(post[0]), int(pre[1]), int(post[1]), _p(y), _stream()), "m3_pad2d")
     return y

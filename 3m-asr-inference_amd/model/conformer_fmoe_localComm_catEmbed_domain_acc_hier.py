@@ -114,8 +114,9 @@ def emit_attention(nh, sd, p, x, x_len, pos_emb, h):
     return nh.addLinear(_linear(sd, p + "linear_out."), ctx)
 
 
-def emit_conv_module(nh, sd, p, x, x_len, kernel, norm):
-    """ConvolutionModule.forward (layer/convolution.py:83-167)."""
+def emit_conv_module(nh, sd, p, x, x_len, kernel, norm, causal=False):
+    """ConvolutionModule.forward (layer/convolution.py:83-167); causal: lorder = kernel - 1 frames of zeros in front of
+    pointwise_conv1 through network.add_padding, depthwise conv without padding (:43-49,118-123)."""
     def masked(t):
         plugin = _plugin(nh, "MaskedFillPluginDynamic", [("data_type", _dtype(nh)), ("fill", 0.0)])
         layer = nh.network.add_plugin_v2([t, x_len], plugin)
@@ -125,8 +126,12 @@ def emit_conv_module(nh, sd, p, x, x_len, kernel, norm):
     C = x.shape[-1]
     x = masked(nh.addShuffle(x, (0, 2, 1), None, None, "conv_trans"))
     x = nh.addShuffle(x, None, (0, 0, 1, -1), None, "conv_trans_3d_to_4d")
+    if causal:
+        layer = nh.network.add_padding(x, pre_padding=(0, kernel - 1), post_padding=(0, 0))
+        nh.set_layer_name(layer, "conv_pad")
+        x = layer.get_output(0)
     x = nh.addGLU(nh.addConv1d(_conv(sd, p + "pointwise_conv1.", (1,), (1,), (0,), 1), x), 1)
-    x = nh.addConv1d(_conv(sd, p + "depthwise_conv.", (kernel,), (1,), ((kernel - 1) // 2,), C), x)
+    x = nh.addConv1d(_conv(sd, p + "depthwise_conv.", (kernel,), (1,), (0 if causal else (kernel - 1) // 2,), C), x)
     if norm != "layer_norm":
         raise RuntimeError("op-by-op emission supports cnn_module_norm='layer_norm' only (the TRT-style forward "
                            "calls addLayerNorm unconditionally, convolution.py:145); batch_norm is folded by the engine")
@@ -167,7 +172,7 @@ def emit_block(nh, sd, p, x, embed, x_len, pos_emb, cfg, heads, norm, moe):
     y = emit_attention(nh, sd, p + "self_attn.", nh.addLayerNorm(_norm(sd, p + "norm_mha.", eps), x), x_len, pos_emb, heads)
     x = nh.addAdd(x, y)
     y = emit_conv_module(nh, sd, p + "conv_module.", nh.addLayerNorm(_norm(sd, p + "norm_conv.", eps), x), x_len,
-                         cfg.cnn_module_kernel, norm)
+                         cfg.cnn_module_kernel, norm, bool(cfg.causal if moe else cfg.embed_causal))
     x = nh.addAdd(x, y, "conv_residual_layer")
     xn = nh.addLayerNorm(_norm(sd, p + "norm_ff.", eps), x)
     y = emit_moe(nh, sd, p + "feed_forward.", xn, embed, x_len, cfg) if moe else emit_ffn(nh, sd, p + "feed_forward.", xn)

@@ -162,7 +162,10 @@ class _Network:
         return _ShuffleLayer(self._h, x)
 
     def add_padding(self, x, pre_padding, post_padding):
-        raise RuntimeError("add_padding (causal conv) not support!")     # lorder > 0 is not on the hot path
+        """trt.INetworkDefinition.add_padding (IPaddingLayer: zeros on the last two dims): the causal ConvolutionModule pads
+        lorder = K - 1 frames on the left of its (B,C,1,T) input (convolution.py:118-123)."""
+        self.num_layers += 1
+        return _Layer([ops.pad2d(self._h._dev(x).contiguous(), tuple(pre_padding), tuple(post_padding))])
 
     def mark_output(self, x):
         self._h.outputs.append(x)
@@ -310,7 +313,7 @@ class NetworkHelper:
             return ops.permute_copy(y.view(B, T, -1), (0, 2, 1)).reshape(B, -1, 1, T)
         if layer.groups == Cin and w.shape[1] == 1 and layer.stride[0] == 1 and layer.dilation[0] == 1:
             y = ops.depthwise_conv1d(x.reshape(B, Cin, T).contiguous(), self._dev(w), b, layer.padding[0])
-            return y.reshape(B, Cin, 1, T)
+            return y.reshape(B, Cin, 1, y.shape[-1])       # (the causal module convolves its own left padding away: padding 0)
         raise RuntimeError("nn.Conv1d with kernel %d / groups %d not support!" % (k, layer.groups))
 
     def addGLU(self, x, axis_dim=-1, layer_name=None, precision=None):
@@ -334,6 +337,22 @@ class NetworkHelper:
         return ops.softmax_lastdim(x)
 
     # ---- network_helper.py (plugin conveniences) ----------------------------------------------
+    def addCatSplitCache(self, cache, x, dim, layer_name=None, precision=None):
+        """plugin CatSplitCache (TRTAPI++/python/trt_helper/network_helper.py:80-105): [cat([cache, x], dim), new cache = the
+        last cache.shape[dim] entries of it along dim]."""
+        plg_creator = self.plugin_registry.get_plugin_creator("CatSplitCachePluginDynamic", "1", "")
+        if not plg_creator:
+            raise RuntimeError("Could not find CatSplitCachePluginDynamic")
+        data_type = trt.PluginField("data_type", np.array([getattr(self.config, "plugin_data_type", 0)], dtype=np.int32), trt.PluginFieldType.INT32)
+        axis = trt.PluginField("axis_dim", np.array([dim], dtype=np.int32), trt.PluginFieldType.INT32)
+        plugin = plg_creator.create_plugin("CatSplitCachePluginDynamic", trt.PluginFieldCollection([data_type, axis]))
+        if not plugin:
+            raise RuntimeError("Could not create_plugin CatSplitCachePluginDynamic")
+        layer = self.network.add_plugin_v2([cache, x], plugin)
+        self.set_layer_name(layer, "CatSplitCachePlugin" if layer_name is None else "CatSplitCachePlugin." + layer_name)
+        return [layer.get_output(0), layer.get_output(1)]
+
+
     def addDumpTensor(self, x, layer_name=None):
         """DumpTensor plugin (dump_tensor_plugin.cpp:79-130): identity + print."""
         t = x.detach().float().cpu()

@@ -330,6 +330,11 @@ int m3_concat_last(const float* a, int da, const float* b, int db, float* y, siz
 int m3_softmax(const float* x, float* y, size_t rows, int n, m3_stream stream);
 int m3_batched_matmul(const float* a, const float* b, float* c, int batch, int M, int N, int K,
                       int64_t stride_a, int64_t stride_b, int transpose_b, m3_stream stream);
+/* zero padding of the last two dims (TensorRT IPaddingLayer; network.add_padding of the causal conv module,
+ * convolution.py:118-123): x (outer, H, W) -> y (outer, H + pre_h + post_h, W + pre_w + post_w) */
+int m3_pad2d(const float* x, size_t outer, int H, int W, int pre_h, int post_h, int pre_w, int post_w, float* y,
+             m3_stream stream);
+/* (B,C,T) -> (B,C,T + 2 pad - K + 1), as nn.Conv1d(groups = C, padding = pad) */
 int m3_depthwise_conv1d(const float* x, const float* w, const float* bias, int B, int C, int T, int K, int pad,
                         float* y, m3_stream stream);
 

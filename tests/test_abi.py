@@ -56,7 +56,8 @@ def test_registry_names_are_the_references(lib_path):
     lib = _lib.load()
     for name in ["FMoEExpertPluginDynamic", "SoftmaxTopKPluginDynamic", "AttMaskedSoftmaxPluginDynamic",
                  "LayerNormPluginDynamic", "MaskedFillPluginDynamic", "GluPluginDynamic",
-                 "MaskConv2dSamplePluginDynamic", "RelPositionalEncodingPluginDynamic"]:
+                 "MaskConv2dSamplePluginDynamic", "RelPositionalEncodingPluginDynamic",
+                 "CatSplitCachePluginDynamic", "AttStreamSoftmaxPluginDynamic"]:   # cat_split_cache_plugin.h:26-27, att_stream_softmax_plugin.h:26-27
         assert lib.m3_registry_lookup(name.encode(), b"1") == 1
         assert lib.m3_registry_lookup(name.encode(), b"2") == 0
     assert lib.m3_registry_lookup(b"NoSuchPlugin", b"1") == 0

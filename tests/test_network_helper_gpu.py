@@ -25,7 +25,7 @@ def _reference_conf(cfg):
     return reference_yaml(cfg)["model_conf"]["encoder_conf"]
 
 
-@pytest.mark.parametrize("name", ["tiny", "mid"])
+@pytest.mark.parametrize("name", ["tiny", "mid", "causal"])
 def test_op_by_op_emission_matches_golden(golden, name):
     cfg, z = golden(name)
     net = Net(cfg.input_dim, cfg.output_dim, **_reference_conf(cfg))
@@ -159,3 +159,55 @@ def test_builder_int8_flag_calibrates_and_writes_an_fp8_arithmetic_plan(tmp_path
     cfgh.use_int8 = True
     with pytest.raises(RuntimeError, match="calibrator is None"):
         trt_helper.BuilderHelper(cfgh, None, None)
+
+
+def test_streaming_plugins_behind_the_reference_surface():
+    """CatSplitCachePluginDynamic / AttStreamSoftmaxPluginDynamic / RelPositionalEncoding(streaming = 1) through the registry,
+    create_plugin, add_plugin_v2 (generic m3_plugin_* C ABI) and network_helper.addCatSplitCache
+    (TRTAPI++/python/trt_helper/network_helper.py:80-105), against the restatements of the kernel text
+    (oracle/ctc_decode.py; parity unpinned: the reference ships no fixture for them and its CUDA cannot be built here)."""
+    from oracle import ctc_decode as ref
+    nh = trt_helper.NetworkHelper(config=trt_helper.HelperConfig())
+    g = torch.Generator().manual_seed(3)
+    # --- addCatSplitCache on a (B, h, T, dk) key cache, along the time axis
+    cache, x = torch.randn(2, 4, 6, 8, generator=g), torch.randn(2, 4, 3, 8, generator=g)
+    out, new_cache = nh.addCatSplitCache(cache.cuda(), x.cuda(), 2)
+    want = torch.cat([cache, x], 2)
+    assert torch.equal(out.cpu(), want) and torch.equal(new_cache.cpu(), want[:, :, -6:])
+    # input longer than the cache (the reference's other kernel pair), last axis by axis_dim = -1
+    cache, x = torch.randn(3, 2, 4, generator=g), torch.randn(3, 2, 9, generator=g)
+    out, new_cache = nh.addCatSplitCache(cache.cuda(), x.cuda(), -1)
+    want = torch.cat([cache, x], 2)
+    assert torch.equal(out.cpu(), want) and torch.equal(new_cache.cpu(), want[:, :, -4:])
+    creator = nh.plugin_registry.get_plugin_creator("CatSplitCachePluginDynamic", "1", "")
+    assert creator.create_plugin("p", trt.PluginFieldCollection([trt.PluginField("data_type", np.array([0], np.int32), trt.PluginFieldType.INT32)])) is None
+    with pytest.raises(RuntimeError):
+        nh.addCatSplitCache(torch.zeros(2, 3).cuda(), torch.zeros(2, 3).cuda(), 1)       # nbDims < 3 (cat_split_cache_plugin.cpp:95-98)
+    # --- AttStreamSoftmax
+    B, H, Tq, ld, cache_len = 2, 4, 5, 21, 16
+    scores = torch.randn(B, H, Tq, ld, generator=g)
+    dfn, mask = torch.tensor([21, 9], dtype=torch.int32), torch.tensor([5, 3], dtype=torch.int32)
+    creator = nh.plugin_registry.get_plugin_creator("AttStreamSoftmaxPluginDynamic", "1", "")
+    plugin = creator.create_plugin("AttStreamSoftmaxPluginDynamic", trt.PluginFieldCollection([
+        trt.PluginField("data_type", np.array([0], np.int32), trt.PluginFieldType.INT32),
+        trt.PluginField("scale", np.array([0.125], np.float32), trt.PluginFieldType.FLOAT32),
+        trt.PluginField("cache_len", np.array([cache_len], np.int32), trt.PluginFieldType.INT32)]))
+    got = nh.network.add_plugin_v2([scores.cuda(), dfn.cuda(), mask.cuda()], plugin).get_output(0).cpu().numpy()
+    want = ref.att_stream_softmax(scores.reshape(B, H * Tq, ld).numpy(), dfn.numpy(), mask.numpy(), cache_len, 0.125).reshape(got.shape)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7)
+    # --- RelPositionalEncoding, streaming = 1: third input = frame counter, pos_emb = pe[offset : offset + T]
+    D, T = 16, 6
+    pe = torch.randn(1, 64, D, generator=g)
+    x = torch.randn(2, T, D, generator=g)
+    fn = torch.tensor([10, 10], dtype=torch.int32)
+    creator = nh.plugin_registry.get_plugin_creator("RelPositionalEncodingPluginDynamic", "1", "")
+    plugin = creator.create_plugin("RelPositionalEncodingPluginDynamic", trt.PluginFieldCollection([
+        trt.PluginField("data_type", np.array([0], np.int32), trt.PluginFieldType.INT32),
+        trt.PluginField("scale", np.array([4.0], np.float32), trt.PluginFieldType.FLOAT32),
+        trt.PluginField("max_len", np.array([64], np.int32), trt.PluginFieldType.INT32),
+        trt.PluginField("dim", np.array([D], np.int32), trt.PluginFieldType.INT32),
+        trt.PluginField("streaming", np.array([1], np.int32), trt.PluginFieldType.INT32)]))
+    layer = nh.network.add_plugin_v2([x.cuda(), pe.cuda(), fn.cuda()], plugin)
+    assert torch.equal(layer.get_output(0).cpu(), x * 4.0) and torch.equal(layer.get_output(1).cpu(), pe[:, 10:10 + T])
+    with pytest.raises(RuntimeError):
+        nh.network.add_plugin_v2([x.cuda(), pe.cuda()], plugin)                             # the frame counter is missing

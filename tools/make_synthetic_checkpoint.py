@@ -19,9 +19,10 @@ def reference_yaml(cfg):
             "model_conf": {"encoder_conf": {
                 "attention_heads": cfg.attention_heads, "attention_dim": cfg.attention_dim, "num_blocks": cfg.num_blocks,
                 "cnn_module_kernel": cfg.cnn_module_kernel, "cnn_module_norm": cfg.cnn_module_norm,
+                "causal": bool(cfg.causal), "static_chunk_size": int(cfg.static_chunk_size),
                 "embed_conf": {"attention_heads": cfg.embed_heads, "attention_dim": cfg.embed_dim,
                                "linear_units": cfg.embed_linear_units, "num_blocks": cfg.embed_blocks,
-                               "cnn_module_norm": cfg.embed_cnn_module_norm},
+                               "cnn_module_norm": cfg.embed_cnn_module_norm, "causal": bool(cfg.embed_causal)},
                 "moe_conf": {"num_experts": cfg.num_experts, "hidden_units": cfg.hidden_units}}}}
 
 
