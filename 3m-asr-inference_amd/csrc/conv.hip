@@ -34,7 +34,9 @@ struct DwCausal {
   const int32_t* chunk_len = nullptr;      // streaming: valid frames of this chunk per utterance
 };
 
-template <int KT>
+// CAUSAL is a template parameter: the symmetric form is the round-3 kernel instruction for instruction (making it a run-time
+// field of one kernel cost 4.9 -> 8.3 us per launch at B = 1: a pointer select in front of every tap load).
+template <int KT, bool CAUSAL>
 __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ gamma,
@@ -46,13 +48,12 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
   __shared__ float red[2][16];
   // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~6 dependent s_load rounds otherwise)
   asm volatile("" ::"s"(z), "s"(w_kc), "s"(bias), "s"(gamma), "s"(beta), "s"(eps), "s"(T), "s"(D), "s"(K), "s"(out), "s"(out_bf16),
-               "s"(pad_of), "s"(row0), "s"(row_len), "s"(n_rows), "s"(cs.causal), "s"(cs.left), "s"(cs.left_b_stride),
-               "s"(cs.left_t_stride), "s"(cs.step), "s"(cs.half), "s"(cs.chunk_len));
+               "s"(pad_of), "s"(row0), "s"(row_len), "s"(n_rows));
   const int row = blockIdx.x;
   const int c = threadIdx.x * 4;
   const bool live = c < D;
   const float* leftp = cs.left;
-  if (cs.step != nullptr) {                         // streaming: read half (step & 1), write the other one
+  if (CAUSAL && cs.step != nullptr) {                         // streaming: read half (step & 1), write the other one
     const int par = *cs.step & 1;
     leftp = cs.left + (size_t)par * cs.half;
     if (row >= n_rows) {                            // cache update: row i of utterance b <- frame i + len of [cache | z]
@@ -81,8 +82,8 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
     r0 = (size_t)row0[b];
     rpad = (size_t)row0[n_rows / T];                  // P = row0[B]
   }
-  const int pad = cs.causal ? K - 1 : (K - 1) / 2;
-  if (cs.causal) leftp += (size_t)b * cs.left_b_stride + (size_t)(K - 1) * cs.left_t_stride;   // frame tt < 0 is leftp + tt * left_t_stride
+  const int pad = CAUSAL ? K - 1 : (K - 1) / 2;
+  if (CAUSAL) leftp += (size_t)b * cs.left_b_stride + (size_t)(K - 1) * cs.left_t_stride;   // frame tt < 0 is leftp + tt * left_t_stride
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
   if (live) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
         const int tt = t + k - pad;
         const int tc = min(max(tt, 0), T - 1);
         const float* src = z + (tc < len ? r0 + tc : rpad) * D;
-        if (cs.causal) {                              // no taps to the right; frames left of the utterance come from `left`
+        if (CAUSAL) {                                 // no taps to the right; frames left of the utterance come from `left`
           on[kk] = (k0 + kk < K) ? 1.f : 0.f;
           if (tt < 0) src = leftp + (long)tt * cs.left_t_stride;
         } else {
@@ -163,12 +164,12 @@ static int launch_dwconv_impl(const float* z, const float* w_kc, const float* bi
   if (rows == 0) return 0;
   const int threads = (int)align_up(D / 4, 64);
   const int grid = rows + (cs.step != nullptr ? B * (K - 1) : 0);     // streaming: + the work-groups that write the new cache
-  if (K <= 15)
-    hipLaunchKernelGGL((dwconv_ln_silu_kernel<15>), dim3(grid), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len, rows, cs);
-  else
-    hipLaunchKernelGGL((dwconv_ln_silu_kernel<8>), dim3(grid), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta,
-                       eps, T, D, K, out, out_bf16, pad_of, row0, row_len, rows, cs);
+#define M3_DW_CASE(KT_, C_)                                                                                                  \
+  hipLaunchKernelGGL((dwconv_ln_silu_kernel<KT_, C_>), dim3(grid), dim3(threads), 0, stream, z, w_kc, bias, gamma, beta, eps, T, \
+                     D, K, out, out_bf16, pad_of, row0, row_len, rows, cs)
+  if (K <= 15) { if (cs.causal) M3_DW_CASE(15, true); else M3_DW_CASE(15, false); }
+  else { if (cs.causal) M3_DW_CASE(8, true); else M3_DW_CASE(8, false); }
+#undef M3_DW_CASE
   M3_LAUNCH_CHECK();
   return 0;
 }

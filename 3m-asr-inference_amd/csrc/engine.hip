@@ -141,6 +141,12 @@ int gate_index_max_rows() {
   return v;
 }
 
+// M3_SELF_ROUTE=0 puts the single-work-group SoftmaxTopK + ScatterMapping launch back in front of the B = 1 expert launch (read once)
+bool self_route_enabled() {
+  static const bool v = [] { const char* e = getenv("M3_SELF_ROUTE"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+
 // dtype: what the engine will read the tensor as (GEMM weights follow cfg.weight_dtype, everything else is fp32)
 bool lookup(const m3_engine* e, const std::string& name, int64_t numel, const float** out, int dtype = M3_F32) {
   auto it = e->table.find(name);
@@ -650,6 +656,9 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float *ew1 = w.ew1, *eb1 = w.eb1, *ew2 = w.ew2, *eb2 = w.eb2;
     const float* fg = w.n_final.g; const float* fb = w.n_final.b;
     const float* gv = c.keep_expert_output ? nullptr : gval;
+    // S <= 256 rows, all experts local, fp32, staged route: the expert launch routes for itself (M3_SELF_ROUTE=0: index launch as before)
+    const bool self_route = self_route_enabled() && c.fuse_route == 0 && world == 1 && c.ep_stages <= 0 && c.weight_dtype == M3_F32 &&
+                            expert_ffn_f32_self_routing(S, Etot) && !expert_ffn_f32_tiled(S, E, D, F);
     const bool fused_route = c.fuse_route == 1 && world == 1 && S <= 256 && (E == 16 || E == 32 || E == 64);
     // fuse_route = 2 ("split route"): the embed half of every layer's router product comes from one GEMM per forward
     // ("router_e_all"), the x half is a K = D GEMM with norm_ff folded in (output-side LayerNorm, the embed half added as
@@ -769,6 +778,14 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       e->cur.buffers["ep.wire_b"] = Buf{wire_b, (size_t)R * D * 4};
     } else {
     // "moe_local.*": index + grouped expert FFN + combine with all experts local
+    if (self_route) {
+      // short inputs, fp32: SoftmaxTopK + ScatterMapping happen inside the expert launch (every work-group derives its
+      // expert's rows from the router logits; moe_expert.hip "self-routing form") -- no index launch
+      add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+        return launch_expert_route_ffn_f32(xn, D, rl, live_len, live_rpb, S, E, D, F, ew1, eb1, ew2, 1, eb2, mw.slab, gidx, gval,
+                                           mw.mapping, mw.acc, mw.pos, s);
+      }, stage_info("expert_ffn_f32_kernel", 1, -1.0, 4.0 * D * F * S));
+    } else {
     if (S <= gate_index_max_rows() && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64)) {
       // SoftmaxTopK plugin + ScatterMapping kernel of the reference in ONE launch (a single workgroup: right for a
       // few hundred rows; long batches take the row-parallel top-1 kernel + the index kernel below)
@@ -797,14 +814,18 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
                   1, -1.0, 4.0 * D * F * S));
     }
     }
+    }
     if (!(world > 1 || c.ep_stages > 0)) {
     // long batches run the expert FFN as two grouped GEMMs whose result is ONE slab of sorted rows (never with fused_route: S <= 256)
     const bool e16c = c.weight_dtype != M3_F32;
     const int wmode_c = c.weight_dtype == M3_FP8 ? (w.h_scale > 0.f ? 3 : 2) : 1;
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_w16_rows(wmode_c, mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_w16_slices(wmode_c, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
+    // (self-routing expert launch: slabs hold ORIGINAL rows with b2 already in slice 0 -> no mapping, no b2 here)
+    const int32_t* cmap = self_route ? nullptr : mw.mapping;
+    const float* cb2 = self_route ? nullptr : eb2;
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
-      return launch_moe_combine(erows, eslices, mw.mapping, gidx, gv, eb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
+      return launch_moe_combine(erows, eslices, cmap, gidx, gv, cb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
                                 dma ? xstats : nullptr);
     }, stage_info("moe_combine_kernel", 1, (double)S * D * 4 * (eslices + 2) + (a16 ? 2.0 * S * D : 0.0), (double)S * D * (eslices + 10)));
     }

@@ -44,9 +44,12 @@ constexpr int kImageBytes = DBM * kCLd * 4;
 constexpr int dma_lds_bytes(int stages) { return stages * kStageBytes > kImageBytes ? stages * kStageBytes : kImageBytes; }
 
 // LDS-DMA fill, hidden from hipcc's waitcnt pass (see the header): 64 lanes x 16 B land at lds_addr + 16 lane
+// (M0 is not on the clobber list: it is a RESERVED register for hipcc -- naming it draws "clobber list contains reserved
+//  registers: m0 ... may lead to undefined behaviour"; the compiler never keeps a value live in M0 across statements, it
+//  re-materialises M0 in front of each of its own uses (LDS-DMA / s_movrel lowering), which is what makes this safe.)
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, size_t bytes) {
   const unsigned long long a = (unsigned long long)base;

@@ -157,6 +157,12 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
                                   int D, int F, const void* w1, const float* b1, const void* w2, int w2_sliced,
                                   void* hbuf, float* ybuf, hipStream_t stream, const float* b2 = nullptr, float* y_scatter = nullptr);
 // out[s] = resid[s] + alpha * gate[s] * (b2[g_s] + sum_slices slab[slice][mapping[s]]), optional LayerNorm after
+// SoftmaxTopK + ScatterMapping + grouped expert FFN in ONE launch (S <= 256 rows, all experts local, fp32): see moe_expert.hip
+bool expert_ffn_f32_self_routing(int S, int E);
+int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, const int32_t* row_len, int rows_per_batch, int S, int E,
+                                int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, const float* b2,
+                                float* slab, int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
+                                hipStream_t stream);
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,

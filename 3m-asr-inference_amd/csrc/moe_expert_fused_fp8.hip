@@ -63,7 +63,7 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // fills themselves are written by hand (wait_vmcnt below).
 __device__ __forceinline__ void dma16_hidden(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");   // (m0 is reserved: hipcc re-loads it before its own uses)
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");   // (m0 is reserved: hipcc re-loads it before its own uses)
 }
 // Y leaves through stores hipcc does not see either: with loads AND stores pending in its model (gfx9 counts both in vmcnt
 // and they may complete out of order), every later wait for a load becomes s_waitcnt vmcnt(0) until a vmcnt(0) is executed

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "moe_gate.h"
 
 namespace m3 {
 
@@ -32,43 +33,6 @@ __device__ __forceinline__ unsigned long long match_expert(int key, bool active,
     mask &= bit ? bal : ~bal;
   }
   return active ? mask : 0ull;
-}
-
-// Router gate on one lane: softmax + top-1 over WIDTH logits with the reference's arg-max tree
-// (SoftmaxAndTop1KernelSmall, softmax_topk_kernel.cu:55-64: stride tree, strict '<').
-template <int WIDTH>
-__device__ __forceinline__ void gate_top1_lane(const float* __restrict__ row, int* idx_out, float* val_out) {
-  constexpr int H = WIDTH / 2;
-  float v[H];
-  int id[H];
-  // first tree stage (stride WIDTH/2) while loading, so only WIDTH/2 candidates stay in registers
-#pragma unroll
-  for (int j = 0; j < H; j += 4) {
-    const f32x4 lo = ldg4(row + j), hi = ldg4(row + H + j);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool take_hi = lo[q] < hi[q];
-      v[j + q] = take_hi ? hi[q] : lo[q];
-      id[j + q] = take_hi ? H + j + q : j + q;
-    }
-  }
-#pragma unroll
-  for (int stride = H >> 1; stride > 0; stride >>= 1)
-#pragma unroll
-    for (int t = 0; t < stride; ++t)
-      if (v[t] < v[t + stride]) {
-        v[t] = v[t + stride];
-        id[t] = id[t + stride];
-      }
-  float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < WIDTH; j += 4) {   // second pass over the row (L1-resident)
-    const f32x4 t = ldg4(row + j);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sum += expf(t[q] - v[0]);
-  }
-  *idx_out = id[0];
-  *val_out = 1.f / sum;
 }
 
 // Stable counting sort of the tokens by expert (see the header comment).  `gate` may point to global memory or to

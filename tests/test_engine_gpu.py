@@ -122,7 +122,8 @@ def test_fused_and_staged_route_paths_agree():
     b = Engine.from_state_dict(cfg, w, fuse_route=False, packed_rows=False)      # same (padded) row layout for the taps
     ya, yb = a(feat, fl).clone(), b(feat, fl).clone()
     assert "blocks.0.moe_route" in a.stage_names() and "blocks.0.moe_router" in b.stage_names()
-    assert a.num_kernels() < b.num_kernels()
+    # (the staged path of short fp32 inputs routes inside the expert launch since round 4: no index launch there either)
+    assert not any(n.endswith("moe_gate_index") for n in b.stage_names())
     for i in range(cfg.num_blocks):
         assert torch.equal(a.buffer("blocks.%d.gate_idx" % i, torch.int32), b.buffer("blocks.%d.gate_idx" % i, torch.int32))
     assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
