@@ -103,7 +103,11 @@ int launch_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, in
                         hipStream_t stream);
 
 // ---- grouped expert FFN (moe_expert.hip) ----
-constexpr int kExpertSlice = 64;  // hidden units per workgroup (16 per wave); m3asr/plan.py EXPERT_SLICE must match
+#ifndef M3_EXPERT_SLICE
+#define M3_EXPERT_SLICE 64        // (16 / 32: experiment builds next to the tree, tools/exp_ffn_pair.py; the plan format assumes 64)
+#endif
+constexpr int kExpertSliceW16 = 64;            // the bf16 / e4m3 slab kernels are laid out for 64-wide slices
+constexpr int kExpertSlice = M3_EXPERT_SLICE;  // hidden units per workgroup (16 per wave); m3asr/plan.py EXPERT_SLICE must match
 size_t expert_ffn_slab_bytes(int S, int D, int F);
 int init_expert_ffn_kernels();
 int launch_expert_ffn_f32(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E,

@@ -15,7 +15,7 @@
 namespace m3 {
 
 template <int MT>
-__global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_bf16w_kernel(
+__global__ __launch_bounds__(64 * (kExpertSliceW16 / 16)) void expert_ffn_bf16w_kernel(
     const float* __restrict__ x, int ldx, const int32_t* __restrict__ pos, const int32_t* __restrict__ acc_hist, int S,
     int D, int F, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2,
     int w2_row_stride, int w2_slice_stride, float* __restrict__ slab) {
@@ -27,14 +27,14 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_bf16w_ker
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int xs_ld = D + 8;                    // bf16 elements; +16 B keeps the 16-B fragment reads spread over banks
-  constexpr int hs_ld = kExpertSlice + 8;
-  constexpr int NWV = kExpertSlice / 16;      // 4 waves, 16 hidden units each
-  constexpr int KS2 = kExpertSlice / 32;      // 32-deep k-steps of phase 2 (2)
+  constexpr int hs_ld = kExpertSliceW16 + 8;
+  constexpr int NWV = kExpertSliceW16 / 16;      // 4 waves, 16 hidden units each
+  constexpr int KS2 = kExpertSliceW16 / 32;      // 32-deep k-steps of phase 2 (2)
   constexpr int SPG = 8 / KS2;                // phase-2 output tiles per 8-load group (4)
-  static_assert(kExpertSlice == 64, "bf16 expert kernel is laid out for 64-wide slices");
+  static_assert(kExpertSliceW16 == 64, "bf16 expert kernel is laid out for 64-wide slices");
   bf16_t* xs = reinterpret_cast<bf16_t*>(lds_raw);   // [16*MT][D+8]
   bf16_t* hs = xs + 16 * MT * xs_ld;                 // [16*MT][64+8]
-  const int f0 = slice * kExpertSlice;
+  const int f0 = slice * kExpertSliceW16;
   const int ksteps1 = D >> 5;
 
   const bf16_t* w1row = w1 + ((size_t)e * F + f0 + 16 * wave + col) * D + 8 * kq;
@@ -169,7 +169,7 @@ bool expert_ffn_bf16_tiled(int S, int E, int D, int F) {
 float* expert_ffn_bf16_rows(float* slab, int S, int E, int D, int F) {   // what moe_combine reads
   return expert_ffn_bf16_tiled(S, E, D, F) ? (float*)((char*)slab + align_up((size_t)S * F * 2, 256)) : slab;
 }
-int expert_ffn_bf16_slices(int S, int E, int D, int F) { return expert_ffn_bf16_tiled(S, E, D, F) ? 1 : F / kExpertSlice; }
+int expert_ffn_bf16_slices(int S, int E, int D, int F) { return expert_ffn_bf16_tiled(S, E, D, F) ? 1 : F / kExpertSliceW16; }
 
 // fp8 arithmetic (wmode 3) takes the fused one-kernel form where it applies (its result: fsplit slabs of sorted rows at the
 // start of the slab region); bf16 and fp8 weight-only experts keep the layouts above
@@ -208,22 +208,22 @@ int launch_expert_ffn_bf16w(const float* x, int ldx, const int32_t* pos, const i
                             hipStream_t stream, const float* b2, float* y_scatter) {
   M3_REQUIRE(S > 0 && E > 0, "expert_ffn_bf16w: empty problem S=%d E=%d", S, E);
   M3_REQUIRE((D & 31) == 0 && D <= 2048, "expert_ffn_bf16w: idim=%d must be a multiple of 32 (<=2048)", D);
-  M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
+  M3_REQUIRE(F % kExpertSliceW16 == 0, "expert_ffn_bf16w: hidden_units=%d must be a multiple of %d", F, kExpertSliceW16);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_bf16w: ldx=%d must be a multiple of 4", ldx);
   if (expert_ffn_bf16_tiled(S, E, D, F))
     return launch_expert_ffn_bf16w_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, slab,
                                          expert_ffn_bf16_rows(slab, S, E, D, F), stream, b2, y_scatter);
   M3_REQUIRE(y_scatter == nullptr, "expert_ffn_bf16w: the scattering epilogue exists in the tiled form only (S=%d E=%d)", S, E);
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
-  const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(bf16_t);
+  const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSliceW16 + 8)) * sizeof(bf16_t);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn_bf16w: LDS tile of %zu bytes does not fit", lds_bytes);
   int zt = cdiv(S, 16 * mt);
-  dim3 grid(F / kExpertSlice, E, zt < 8 ? zt : 8);
-  const int w2_row_stride = w2_sliced ? kExpertSlice : F;
-  const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
+  dim3 grid(F / kExpertSliceW16, E, zt < 8 ? zt : 8);
+  const int w2_row_stride = w2_sliced ? kExpertSliceW16 : F;
+  const int w2_slice_stride = w2_sliced ? D * kExpertSliceW16 : kExpertSliceW16;
   if (int rc = init_expert_ffn_bf16_kernels()) return rc;
 #define M3_EXPERT_CASE(MT_)                                                                                       \
-  hipLaunchKernelGGL((expert_ffn_bf16w_kernel<MT_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, \
+  hipLaunchKernelGGL((expert_ffn_bf16w_kernel<MT_>), grid, dim3(64 * (kExpertSliceW16 / 16)), lds_bytes, stream, x, \
                      ldx, pos, acc_hist, S, D, F, (const bf16_t*)w1, b1, (const bf16_t*)w2, w2_row_stride,        \
                      w2_slice_stride, slab)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);

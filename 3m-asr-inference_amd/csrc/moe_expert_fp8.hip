@@ -20,7 +20,7 @@
 namespace m3 {
 
 template <int MT>
-__global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_w8_kernel(
+__global__ __launch_bounds__(64 * (kExpertSliceW16 / 16)) void expert_ffn_w8_kernel(
     const float* __restrict__ x, int ldx, const int32_t* __restrict__ pos, const int32_t* __restrict__ acc_hist, int S,
     int D, int F, const uint8_t* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ b1,
     const uint8_t* __restrict__ w2, const float* __restrict__ s2, int w2_row_stride, int w2_slice_stride,
@@ -33,12 +33,12 @@ __global__ __launch_bounds__(64 * (kExpertSlice / 16)) void expert_ffn_w8_kernel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int xs_ld = D + 8;
-  constexpr int hs_ld = kExpertSlice + 8;
-  constexpr int NWV = kExpertSlice / 16;
-  static_assert(kExpertSlice == 64, "laid out for 64-wide slices");
+  constexpr int hs_ld = kExpertSliceW16 + 8;
+  constexpr int NWV = kExpertSliceW16 / 16;
+  static_assert(kExpertSliceW16 == 64, "laid out for 64-wide slices");
   bf16_t* xs = reinterpret_cast<bf16_t*>(lds_raw8);   // [16*MT][D+8]
   bf16_t* hs = xs + 16 * MT * xs_ld;                  // [16*MT][64+8]
-  const int f0 = slice * kExpertSlice;
+  const int f0 = slice * kExpertSliceW16;
   const int kd1 = D >> 6;                             // 64-deep double steps of phase 1
   const int n1 = f0 + 16 * wave + col;                // this lane's hidden unit
 
@@ -185,21 +185,21 @@ int launch_expert_ffn_w8(const float* x, int ldx, const int32_t* pos, const int3
                          int w2_sliced, float* slab, hipStream_t stream) {
   M3_REQUIRE(S > 0 && E > 0, "expert_ffn_w8: empty problem S=%d E=%d", S, E);
   M3_REQUIRE((D & 63) == 0 && D <= 2048, "expert_ffn_w8: idim=%d must be a multiple of 64 (<=2048)", D);
-  M3_REQUIRE(F % kExpertSlice == 0, "expert_ffn_w8: hidden_units=%d must be a multiple of %d", F, kExpertSlice);
+  M3_REQUIRE(F % kExpertSliceW16 == 0, "expert_ffn_w8: hidden_units=%d must be a multiple of %d", F, kExpertSliceW16);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_w8: ldx=%d must be a multiple of 4", ldx);
   if (expert_ffn_bf16_tiled(S, E, D, F))
     return launch_expert_ffn_w8_tiled(x, ldx, pos, acc_hist, S, E, D, F, w1, s1, b1, w2, s2, w2_sliced, slab,
                                       expert_ffn_bf16_rows(slab, S, E, D, F), stream);
   const int mt = S <= 64 ? 1 : (S <= 512 ? 2 : 4);
-  const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSlice + 8)) * sizeof(bf16_t);
+  const size_t lds_bytes = (size_t)16 * mt * ((D + 8) + (kExpertSliceW16 + 8)) * sizeof(bf16_t);
   M3_REQUIRE(lds_bytes <= 160 * 1024, "expert_ffn_w8: LDS tile of %zu bytes does not fit", lds_bytes);
   int zt = cdiv(S, 16 * mt);
-  dim3 grid(F / kExpertSlice, E, zt < 8 ? zt : 8);
-  const int w2_row_stride = w2_sliced ? kExpertSlice : F;
-  const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
+  dim3 grid(F / kExpertSliceW16, E, zt < 8 ? zt : 8);
+  const int w2_row_stride = w2_sliced ? kExpertSliceW16 : F;
+  const int w2_slice_stride = w2_sliced ? D * kExpertSliceW16 : kExpertSliceW16;
   if (int rc = init_expert_ffn_w8_kernels()) return rc;
 #define M3_EXPERT_CASE(MT_)                                                                                           \
-  hipLaunchKernelGGL((expert_ffn_w8_kernel<MT_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, pos, \
+  hipLaunchKernelGGL((expert_ffn_w8_kernel<MT_>), grid, dim3(64 * (kExpertSliceW16 / 16)), lds_bytes, stream, x, ldx, pos, \
                      acc_hist, S, D, F, (const uint8_t*)w1, s1, b1, (const uint8_t*)w2, s2, w2_row_stride,             \
                      w2_slice_stride, slab)
   if (mt == 1) M3_EXPERT_CASE(1); else if (mt == 2) M3_EXPERT_CASE(2); else M3_EXPERT_CASE(4);
