@@ -665,6 +665,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // the epilogue residual) instead of the K = De + D GEMM with a LayerNorm prologue, and the expert kernel applies
     // norm_ff while it gathers rows, so xn is never materialised
     const bool split_route = c.fuse_route == 2 && world == 1 && S < 1024 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
+    bool router_gate = false;   // the dedicated router kernel also did SoftmaxTopK (no moe_top1 stage)
     if (split_route) {
       GemmParams r;
       r.A = x; r.lda = D; r.W = w.router_x.w; r.bias = w.router_x.b; r.ln_wsum = w.router_x.wsum; r.ln_eps = eps;
@@ -701,11 +702,14 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // 8.83 -> 8.52 ms; configs[2] 14.1 vs 14.9 us and B = 1 +1.5 us per layer: there the 16-column work-groups of gemm.hip
     // spread the 128-KB weight pull over more CUs).  M3_ROUTER_MIN_ROWS overrides (read once).
     static const int router_min_rows = [] { const char* ev = getenv("M3_ROUTER_MIN_ROWS"); return ev ? atoi(ev) : 2048; }();
+    router_gate = moe_router_supports(De, D, Etot) && S >= router_min_rows && moe_router_fuses_top1(Etot) && S > gate_index_max_rows();
     if (moe_router_supports(De, D, Etot) && S >= router_min_rows) {
       // the dedicated kernel: one work-group per 16 rows and all experts, every activation byte read once (moe_router.hip)
       const float* emb = pl.emb; const float* rw = w.router.w; const float* rb = w.router.b;
       add_stage(e, pfx + "moe_router", 1, [=](hipStream_t s) {
-        return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn, D, rl, Etot, S, Etot, pdev, s);
+        // (+ SoftmaxTopK in its tail when the row-parallel top-1 launch would follow: gate_idx / gate_value come from here)
+        return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn, D, rl, Etot, S, Etot, pdev, s,
+                                 router_gate ? gidx : nullptr, router_gate ? gval : nullptr, live_len, live_rpb);
       }, stage_info("moe_router_kernel", 1, (double)Etot * (De + D) * 4 + (double)S * (De + 2 * D + Etot) * 4, 2.0 * S * Etot * (De + D)));
     } else {
       add_gemm(e, pfx + "moe_router", r, true);
@@ -725,7 +729,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
           return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, g_map, g_acc, g_pos, s);
         }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (Etot + 1), 0.0));
-      } else {
+      } else if (!router_gate) {
         add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
           return launch_softmax_top1(rl, Etot, live_len, live_rpb, S, Etot, gidx, gval, s);
         }, stage_info("softmax_top1_kernel", 1, (double)S * (Etot * 4 + 8), 0.0));
@@ -793,6 +797,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
       }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (E + 1), 0.0));
     } else {
+      if (!router_gate)
       add_stage(e, pfx + "moe_top1", 1, [=](hipStream_t s) {
         return launch_softmax_top1(rl, Etot, live_len, live_rpb, S, Etot, gidx, gval, s);
       }, stage_info("softmax_top1_kernel", 1, (double)S * (Etot * 4 + 8), 0.0));

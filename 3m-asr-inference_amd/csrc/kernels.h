@@ -87,10 +87,12 @@ int launch_moe_route(const float* x, int ldx, int D, const float* wx, const floa
 // router product on cat([embed, LayerNorm(x)]) with the normalised rows written out (moe_router.hip): one work-group per 16
 // rows and all N <= 64 experts
 bool moe_router_supports(int De, int D, int N);
+bool moe_router_fuses_top1(int N);   // SoftmaxTopK in the router kernel's tail (gate_idx / gate_val arguments of launch_moe_router)
 int init_moe_router_kernels();
 int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx, int D, const float* W, const float* bias,
                       const float* gamma, const float* beta, float eps, float* xn, int ldxn, float* Y, int ldy, int M, int N,
-                      const int32_t* m_dev, hipStream_t stream);
+                      const int32_t* m_dev, hipStream_t stream, int32_t* gate_idx = nullptr, float* gate_val = nullptr,
+                      const int32_t* row_len = nullptr, int rows_per_batch = 0);
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 

@@ -15,6 +15,7 @@
 // fp32 in every engine mode: a flipped top-1 is a discrete error.
 #include "common.h"
 #include "kernels.h"
+#include "moe_gate.h"
 
 namespace m3 {
 
@@ -25,12 +26,20 @@ __global__ __launch_bounds__(256, 2) void moe_router_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, float* __restrict__ xn, int ldxn,
                                                             float* __restrict__ Y, int ldy, int M, int N,
-                                                            const int32_t* __restrict__ m_dev) {
+                                                            const int32_t* __restrict__ m_dev,
+                                                            int32_t* __restrict__ gate_idx, float* __restrict__ gate_val,
+                                                            const int32_t* __restrict__ row_len, int rows_per_batch) {
   extern __shared__ __attribute__((aligned(16))) float rt_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16;
-  if (m_dev != nullptr && m0 > *m_dev) return;        // packed ragged batch: no live row in this tile
+  if (m_dev != nullptr && m0 > *m_dev) {              // packed ragged batch: no live row in this tile
+    if (gate_idx != nullptr && blockIdx.y == 0 && threadIdx.x < 16 && m0 + (int)threadIdx.x < M) {   // (its rows are "padding" for the gate)
+      gate_idx[m0 + threadIdx.x] = -1;
+      gate_val[m0 + threadIdx.x] = 0.f;
+    }
+    return;
+  }
   // short inputs have few row tiles: the expert columns are then split over blockIdx.y (each work-group normalises its rows
   // itself -- 16 rows, cheap -- and only column group 0 writes xn), so that more CUs pull W
   const int col_group = blockIdx.y, n_base = col_group * 16 * NT;
@@ -191,9 +200,29 @@ __global__ __launch_bounds__(256, 2) void moe_router_kernel(const float* __restr
                         (red[(2 * NT + t) * 256 + r * 64 + lane] + red[(3 * NT + t) * 256 + r * 64 + lane]);
       const int m = m0 + 4 * kq + r;
       if (m < M && n < N) Y[(size_t)m * ldy + n] = sum + b;
+      if (gate_idx != nullptr) red[4 * NT * 256 + (4 * kq + r) * (16 * NT) + 16 * t + col] = sum + b;   // logits tile [16][16 NT]
+    }
+  }
+  // ---- phase 4 (gate_idx != null; this work-group holds ALL N = 16 NT columns): SoftmaxTopK on the 16 rows, one lane each
+  //      (softmax_topk_kernel.cu:26-120: the reference's arg-max tree, value = 1 / sum exp(x - max); padded frames idx -1 /
+  //      value 0) -- the row-parallel top-1 launch behind the router disappears ----
+  if (gate_idx != nullptr) {
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const int m = m0 + threadIdx.x;
+      if (m < M) {
+        int gi = -1;
+        float gv = 0.f;
+        const bool live = row_len == nullptr || (m % rows_per_batch) < row_len[m / rows_per_batch];
+        if (live) gate_top1_lane<16 * NT>(red + 4 * NT * 256 + threadIdx.x * (16 * NT), &gi, &gv);
+        gate_idx[m] = gi;
+        gate_val[m] = gv;
+      }
     }
   }
 }
+
+bool moe_router_fuses_top1(int N) { return N == 16 || N == 32 || N == 64; }   // whole rows in one work-group, N = 16 NT
 
 bool moe_router_supports(int De, int D, int N) {
   return N >= 1 && N <= 64 && (De & 63) == 0 && (D & 63) == 0 && De >= 64 && D >= 64 && De <= 1024 && D <= 1024;
@@ -204,7 +233,7 @@ bool moe_router_supports(int De, int D, int N) {
 #endif
 constexpr size_t kRouterLdsFloor = M3_ROUTER_LDS_FLOOR;
 static size_t router_lds_bytes(int De, int D, int NT) {
-  const size_t tiles = (size_t)16 * (De + 8 + D + 8) * 4, red = (size_t)4 * NT * 256 * 4;
+  const size_t tiles = (size_t)16 * (De + 8 + D + 8) * 4, red = (size_t)(4 * NT * 256 + 16 * 16 * NT) * 4;   // (+ the logits tile of phase 4)
   return tiles > red ? tiles : red;
 }
 
@@ -221,7 +250,8 @@ int init_moe_router_kernels() {
 
 int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx, int D, const float* W, const float* bias,
                       const float* gamma, const float* beta, float eps, float* xn, int ldxn, float* Y, int ldy, int M, int N,
-                      const int32_t* m_dev, hipStream_t stream) {
+                      const int32_t* m_dev, hipStream_t stream, int32_t* gate_idx, float* gate_val, const int32_t* row_len,
+                      int rows_per_batch) {
   M3_REQUIRE(M > 0 && moe_router_supports(De, D, N), "moe_router: unsupported problem M=%d De=%d D=%d N=%d", M, De, D, N);
   M3_REQUIRE((lde & 3) == 0 && (ldx & 3) == 0 && (xn == nullptr || (ldxn & 3) == 0), "moe_router: row strides must be multiples of 4");
   M3_REQUIRE(emb && x && W && gamma && beta && Y, "moe_router: null pointer");
@@ -229,7 +259,14 @@ int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx
   // column tiles per work-group: all of them (A read once) when the row tiles alone fill the chip, fewer for short inputs
   const int tiles = cdiv(N, 16), rows16 = cdiv(M, 16);
   int nt = tiles <= 1 ? 1 : (tiles == 2 ? 2 : 4);
-  while (nt > 1 && (long)rows16 * cdiv(tiles, nt) < 192) nt >>= 1;
+  const bool top1 = gate_idx != nullptr;
+  if (top1) {   // SoftmaxTopK in the kernel's tail: the work-group must hold whole logits rows, i.e. all column tiles
+    M3_REQUIRE(moe_router_fuses_top1(N) && gate_val != nullptr && (row_len == nullptr || rows_per_batch > 0),
+               "moe_router: fused top-1 needs 16 / 32 / 64 experts (got %d) and a gate_value buffer", N);
+    nt = tiles;
+  } else {
+    while (nt > 1 && (long)rows16 * cdiv(tiles, nt) < 192) nt >>= 1;
+  }
   // Two work-groups per CU.  (Round 3: under concurrent execution contexts this kernel returned, about once in 100 forwards,
   // a row whose LayerNorm mean was wrong -- only beside two particular LDS-DMA GEMM launches of ANOTHER context, only when
   // built with packed-FP32 VALU instructions.  Symptom eliminated by building the library without them (Makefile NOPK,
@@ -240,7 +277,7 @@ int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx
   dim3 grid(rows16, cdiv(tiles, nt));
 #define M3_ROUTER_CASE(NT_)                                                                                              \
   hipLaunchKernelGGL((moe_router_kernel<NT_>), grid, dim3(256), lds, stream, emb, lde, De, x, ldx, D, W, bias, gamma, beta, \
-                     eps, xn, ldxn, Y, ldy, M, N, m_dev)
+                     eps, xn, ldxn, Y, ldy, M, N, m_dev, gate_idx, gate_val, row_len, rows_per_batch)
   if (nt == 1) M3_ROUTER_CASE(1); else if (nt == 2) M3_ROUTER_CASE(2); else M3_ROUTER_CASE(4);
 #undef M3_ROUTER_CASE
   M3_LAUNCH_CHECK();

@@ -272,6 +272,21 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
             "kernels_per_forward_native_stages": eng.num_kernels()}
 
 
+def build_info():
+    """Toolchain + the property the packed-FP32 mitigation rests on, read off the BUILT library."""
+    info = {"abi": None, "hipcc": None, "packed_fp32_instructions": None}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import check_device_isa
+        from m3asr import _lib
+        info["abi"] = _lib.load().m3_abi_version()
+        info["hipcc"] = check_device_isa.hipcc_version()
+        info["packed_fp32_instructions"] = check_device_isa.scan(_lib.LIB_PATH)["packed_fp32"]
+    except Exception as ex:       # noqa: BLE001  (llvm-objdump missing on a box: say so, do not fail the measurement)
+        info["error"] = repr(ex)
+    return info
+
+
 def main():
     args = parse()
     downgraded = False
@@ -288,6 +303,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # (rank 0 disassembles the built library for the JSON line's `build` entry NOW, ~3 s: not between the timed region and the
+    #  headline line, where a peer that has already left would get this rank killed by the launcher before it prints)
+    build = build_info() if rank == 0 else None
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     if args.dist_backend == "gloo":          # rehearsal: more ranks than devices is fine, they share
         local_rank %= torch.cuda.device_count()
@@ -433,6 +451,19 @@ def main():
     dt = float(np.median(rep_dt))
     ms_per_step = dt / args.steps * 1e3
     phase("timed region done")
+    # the driver's default run times 20 forwards per repeat (20 ms samples): a 200-forward region beside it, same contexts, same
+    # bracketing, reported as config.value_200_steps (never as `value`)
+    long_dt = []
+    if args.steps < 200 and not args.pmc_safe and world == 1:
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(200):
+                ctxs[i % len(ctxs)].forward(use_graph=use_graph)
+            for c in ctxs:
+                c.stream.synchronize()
+            barrier()
+            long_dt.append(time.perf_counter() - t0)
     # latency of one forward when it has the GPU to itself (one context): back-to-back mean, and the distribution of
     # individually hipEvent-timed forwards (events recorded on the engine's own stream, one forward in flight at a time)
     t1 = time.perf_counter()
@@ -577,9 +608,17 @@ def main():
             try:
                 import csv
                 rows_ = list(csv.DictReader(open(os.path.join(ROOT, "profiles", kt_csv))))
+                def grp_of(name_):
+                    # gemm_bf16w_tiled_kernel<TBM, TBN, TBK, GLU, CONV, LN, GRP, W8, A16IN>: GRP = 1 / 2 are the two GROUPED (per-expert)
+                    # GEMMs of the expert FFN, 0 the dense ones -- one template, two families
+                    a_ = name_[name_.index("<") + 1:name_.rindex(">")].split(",") if "<" in name_ and ">" in name_ else []
+                    return int(a_[6]) if "gemm_bf16w_tiled_kernel<" in name_ and len(a_) > 6 and a_[6].strip().isdigit() else 0
                 for r_ in (roofline, roofline_expert):
                     base_ = r_["kernel"].split("<")[0]
                     sel_ = [x for x in rows_ if base_ + "<" in x["Name"] or x["Name"].endswith(base_) or (base_ + "(") in x["Name"]]
+                    if base_ == "gemm_bf16w_tiled_kernel":       # grouped instantiations are the expert launches, the rest the dense family
+                        want_grp_ = "<grouped" in r_["kernel"]
+                        sel_ = [x for x in sel_ if (grp_of(x["Name"]) > 0) == want_grp_]
                     if sel_:
                         calls_ = sum(float(x["Calls"]) for x in sel_)
                         r_["rocprof_avg_launch_us"] = round(sum(float(x["TotalDurationNs"]) for x in sel_) / calls_ / 1e3, 2)
@@ -675,6 +714,8 @@ def main():
                           "packed_rows": bool(B > 1 and eng.packed_rows()), "fork_embed": args.fork_embed,
                           "timed_region": "median of %d repeats of %d forwards" % (len(rep_dt), args.steps),
                           "ms_per_step_repeats": [round(d_ / args.steps * 1e3, 4) for d_ in rep_dt],
+                          "value_200_steps": (round(world * n_frames / (float(np.median(long_dt)) / 200), 1) if long_dt else None),
+                          "build": build,
                           "profiler_downgraded": downgraded,
                           "h_scale_calibrated_on": ("the benchmark batch itself (untimed set-up)" if args.fp8_activations else None)},
                "roofline": roofline, "roofline_expert": roofline_expert, "forward": forward, "cpu_baseline": cpu}

@@ -63,15 +63,16 @@ def test_bench_expert_parallel_rehearsal_two_ranks_one_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--layers", "2",
-            "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    def base_cmd():      # a fresh rendezvous port per invocation (a port just released may still be in TIME_WAIT)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--layers", "2",
+                "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     env = dict(os.environ, OMP_NUM_THREADS="4")
-    r = subprocess.run(base + ["--ep", "--weight-dtype", "bf16", "--batch", "2", "--varlen", "50-500"], capture_output=True,
+    r = subprocess.run(base_cmd() + ["--ep", "--weight-dtype", "bf16", "--batch", "2", "--varlen", "50-500"], capture_output=True,
                        text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -79,7 +80,7 @@ def test_bench_expert_parallel_rehearsal_two_ranks_one_gpu(tmp_path):
     # (the gloo rehearsal stages every exchange through the host: 2 synchronisations per layer; RCCL: none)
     assert line["config"]["wire"]["host_syncs_per_forward"] == 4 and line["config"]["wire"]["collectives_per_forward"] == 4
     assert line["config"]["forward_graph"].startswith("eager: the gloo transport")
-    r = subprocess.run(base + ["--streams", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    r = subprocess.run(base_cmd() + ["--streams", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "replicas x2"
@@ -87,10 +88,10 @@ def test_bench_expert_parallel_rehearsal_two_ranks_one_gpu(tmp_path):
     probe = json.load(open(os.path.join(root, "gpurun_out", "ep_probe_n2.json")))
     assert probe["status"] == "ok" and probe["value"] > 0
     # a failing probe is visible: status "failed" + the exception on stderr and in the file, exit code non-zero when strict
-    r = subprocess.run(base + ["--streams", "2", "--ep-probe-inject-failure", "--ep-probe-strict"], capture_output=True, text=True,
+    r = subprocess.run(base_cmd() + ["--streams", "2", "--ep-probe-inject-failure", "--ep-probe-strict"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode != 0
-    assert [l for l in r.stdout.splitlines() if l.startswith("{")], "the headline line must still be printed"
+    assert [l for l in r.stdout.splitlines() if l.startswith("{")], "the headline line must still be printed; stderr: " + r.stderr[-3000:]
     assert "ep_probe status=failed" in r.stderr and "injected failure" in r.stderr
     assert json.load(open(os.path.join(root, "gpurun_out", "ep_probe_n2.json")))["status"] == "failed"
 
