@@ -288,7 +288,7 @@ struct Plan {
   int32_t *row0, *pad_of; float* xpad; void* xbpad; float* lpk;
   // expert parallel (ep_world_size > 1): send-side index over GLOBAL expert ids, the two wire buffers [world][1 + C][D]
   // and the receive-side gate; the MoE workspace is then sized for the world * (1 + C) rows a rank can receive
-  int32_t *ep_acc, *ep_mapping, *ep_pos, *ep_map_send, *ep_gate_recv; float *wire_a, *wire_b; int ep_cap, ep_rows;
+  int32_t *ep_acc, *ep_mapping, *ep_pos, *ep_map_send, *ep_gate_recv, *ep_overflow; float *wire_a, *wire_b; int ep_cap, ep_rows;
   // fork_embed: the embed encoder runs on its own graph branch beside the main subsampler and block 0 up to its router
   // (conformer_fmoe_..._hier.py:206-215: embed is needed first by blocks.0's router), so it owns a second set of scratch
   bool fork;
@@ -334,14 +334,17 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   p.eall = cv.take<float>((size_t)S * Etot * c.num_blocks);
   p.gate_idx = cv.take<int32_t>((size_t)c.num_blocks * S);
   p.gate_val = cv.take<float>((size_t)c.num_blocks * S);
-  // rows per wire chunk: what the ranks agreed on (m3_engine_set_ep_capacity), at least this rank's own row count
+  // rows per wire chunk: what the ranks agreed on (m3_engine_set_ep_capacity).  0 = this rank's own row count (no row can
+  // be dropped); a smaller agreed capacity is a BOUNDED wire: a chunk that needs more rows reports it in "ep.overflow" and the
+  // driver repeats the forward with a larger one (m3asr/ep.py)
   const bool ep = world > 1 || c.ep_stages > 0;
-  p.ep_cap = ep ? (ep_capacity > S ? ep_capacity : S) : 0;
+  p.ep_cap = ep ? (ep_capacity > 0 ? ep_capacity : S) : 0;
   p.ep_rows = ep ? world * (p.ep_cap + 1) : 0;
   p.moe_ws_bytes = carve_moe_workspace(nullptr, ep ? p.ep_rows : S, c.num_experts, c.attention_dim, c.hidden_units).bytes;
   p.moe_ws = cv.take<char>(p.moe_ws_bytes * (size_t)(c.debug_taps ? c.num_blocks : 1));
-  p.ep_acc = p.ep_mapping = p.ep_pos = p.ep_map_send = p.ep_gate_recv = nullptr; p.wire_a = p.wire_b = nullptr;
+  p.ep_acc = p.ep_mapping = p.ep_pos = p.ep_map_send = p.ep_gate_recv = p.ep_overflow = nullptr; p.wire_a = p.wire_b = nullptr;
   if (ep) {
+    p.ep_overflow = cv.take<int32_t>(64);
     p.ep_acc = cv.take<int32_t>((size_t)Etot + 1);
     p.ep_mapping = cv.take<int32_t>(S);
     p.ep_pos = cv.take<int32_t>(S);
@@ -721,6 +724,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       //      wire [world][1 + C][D]: chunk j = what goes to / came from rank j, header row = E_loc row counts ----
       const int cap = pl.ep_cap, R = pl.ep_rows;
       int32_t *g_acc = pl.ep_acc, *g_map = pl.ep_mapping, *g_pos = pl.ep_pos, *map_send = pl.ep_map_send, *gate_recv = pl.ep_gate_recv;
+      int32_t* ep_overflow = pl.ep_overflow;
       float *wire_a = pl.wire_a, *wire_b = pl.wire_b;
       const MoeWorkspace rw = carve_moe_workspace(mws, R, E, D, F);     // receive side: R wire rows over the E local experts
       // top-1 + local index over GLOBAL expert ids (the same kernel choice by row count as with all experts local)
@@ -738,7 +742,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       add_stage(e, pfx + "moe_ep.send", one_launch ? 1 : 2, [=](hipStream_t s) {
         if (!one_launch)
           if (int rc = launch_moe_index(gidx, S, Etot, g_map, g_acc, g_pos, s)) return rc;
-        return launch_ep_send_rows(gidx, g_map, g_acc, S, world, E, cap, map_send, xn, wire_a, D * 4, s);
+        return launch_ep_send_rows(gidx, g_map, g_acc, S, world, E, cap, map_send, xn, wire_a, D * 4, s, ep_overflow);
       }, stage_info("ep_send_rows_kernel", one_launch ? 1 : 2, (double)S * D * 8 + 24.0 * S, 0.0));
       if (world == 1) add_stage(e, pfx + "moe_ep.exchange1", 0, [=](hipStream_t s) {   // one rank: the all-to-all is a copy
         M3_CHECK_HIP(hipMemcpyAsync(wire_b, wire_a, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
@@ -1026,6 +1030,14 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   if (int rc = init_gemm_f32_splitk_kernels()) return rc;
   const int S = e->cur.S, D = c.attention_dim, De = c.embed_dim;
 
+  if (pl.ep_overflow != nullptr) {   // bounded expert-parallel wire: the overflow report of this forward starts at 0
+    int32_t* ovf = pl.ep_overflow;
+    add_stage(e, "ep.reset", 0, [=](hipStream_t s) {
+      M3_CHECK_HIP(hipMemsetAsync(ovf, 0, sizeof(int32_t), s));
+      return 0;
+    });
+    e->cur.buffers["ep.overflow"] = Buf{ovf, sizeof(int32_t)};
+  }
   // valid lengths after the two stride-2 convs (MaskConv2dSample x2, subsampling.py:119-137)
   {
     // No launch of their own: the packed layout's row plan forms them on its way; otherwise the forward's first kernel (the

@@ -27,7 +27,8 @@ namespace m3 {
 
 __global__ __launch_bounds__(256) void ep_send_map_kernel(const int32_t* __restrict__ gate_idx, const int32_t* __restrict__ mapping,
                                                           const int32_t* __restrict__ acc, int S, int world, int e_loc, int cap,
-                                                          int32_t* __restrict__ map_send, int32_t* __restrict__ wire, int row_words) {
+                                                          int32_t* __restrict__ map_send, int32_t* __restrict__ wire, int row_words,
+                                                          int32_t* __restrict__ overflow) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < world * e_loc) {                     // header of chunk j: rows per local expert of rank j
     const int j = tid / e_loc, i = tid - j * e_loc;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void ep_send_map_kernel(const int32_t* __restr
       const int j = g / e_loc;
       const int off = mapping[s] - acc[j * e_loc];            // position among the rows bound for rank j
       m = off < cap ? j * (cap + 1) + 1 + off : -1;           // (off < cap always holds when cap >= S)
+      if (off >= cap && overflow != nullptr) atomicMax(overflow, off + 1);   // bounded wire: rows the chunk would have needed
     }
     map_send[s] = m;
   }
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void ep_send_map_kernel(const int32_t* __restr
 __global__ __launch_bounds__(256) void ep_send_rows_kernel(const int32_t* __restrict__ gate_idx, const int32_t* __restrict__ mapping,
                                                            const int32_t* __restrict__ acc, int S, int world, int e_loc, int cap,
                                                            int32_t* __restrict__ map_send, const uint4* __restrict__ x, int row16,
-                                                           uint4* __restrict__ wire) {
+                                                           uint4* __restrict__ wire, int32_t* __restrict__ overflow) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == 0)
     for (int t = threadIdx.x; t < world * e_loc; t += blockDim.x) {
@@ -64,6 +66,9 @@ __global__ __launch_bounds__(256) void ep_send_rows_kernel(const int32_t* __rest
       const int j = g / e_loc;
       const int off = mapping[s] - acc[j * e_loc];
       m = off < cap ? j * (cap + 1) + 1 + off : -1;
+      // bounded wire (cap < S): a chunk that would need more rows than it has reports how many; the forward's result is then
+      // invalid and the driver repeats it with a larger capacity (m3asr/ep.py) -- rows are never dropped silently
+      if (off >= cap && overflow != nullptr && lane == 0) atomicMax(overflow, off + 1);
     }
     if (lane == 0) map_send[s] = m;
     if (m >= 0) {
@@ -108,26 +113,26 @@ __global__ __launch_bounds__(256) void ep_recv_gate_kernel(const int32_t* __rest
 }
 
 int launch_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
-                       int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream) {
+                       int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream, int32_t* overflow) {
   M3_REQUIRE(S > 0 && world > 0 && e_loc > 0 && capacity > 0, "ep_send_map: bad sizes S=%d world=%d e_loc=%d capacity=%d", S,
              world, e_loc, capacity);
   M3_REQUIRE((row_bytes & 15) == 0 && row_bytes >= 4 * e_loc, "ep_send_map: a wire row of %d bytes cannot carry %d counts", row_bytes, e_loc);
-  M3_REQUIRE(capacity >= S, "ep_send_map: capacity %d < rows %d (a rank may send all of its rows to one peer)", capacity, S);
+  M3_REQUIRE(capacity >= S || overflow != nullptr, "ep_send_map: capacity %d < rows %d needs an overflow counter (a rank may send all of its rows to one peer)", capacity, S);
   const int n = S > world * e_loc ? S : world * e_loc;
   hipLaunchKernelGGL(ep_send_map_kernel, dim3(min(cdiv(n, 256), 1024)), dim3(256), 0, stream, gate_idx, mapping, acc_hist, S,
-                     world, e_loc, capacity, map_send, (int32_t*)wire, row_bytes / 4);
+                     world, e_loc, capacity, map_send, (int32_t*)wire, row_bytes / 4, overflow);
   M3_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_ep_send_rows(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
-                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream) {
+                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream, int32_t* overflow) {
   M3_REQUIRE(S > 0 && world > 0 && e_loc > 0 && capacity > 0, "ep_send_rows: bad sizes S=%d world=%d e_loc=%d capacity=%d", S,
              world, e_loc, capacity);
   M3_REQUIRE((row_bytes & 15) == 0 && row_bytes >= 4 * e_loc, "ep_send_rows: a wire row of %d bytes cannot carry %d counts", row_bytes, e_loc);
-  M3_REQUIRE(capacity >= S, "ep_send_rows: capacity %d < rows %d (a rank may send all of its rows to one peer)", capacity, S);
+  M3_REQUIRE(capacity >= S || overflow != nullptr, "ep_send_rows: capacity %d < rows %d needs an overflow counter (a rank may send all of its rows to one peer)", capacity, S);
   hipLaunchKernelGGL(ep_send_rows_kernel, dim3(min(cdiv(S, 4), 2048)), dim3(256), 0, stream, gate_idx, mapping, acc_hist, S, world,
-                     e_loc, capacity, map_send, (const uint4*)x, row_bytes / 16, (uint4*)wire);
+                     e_loc, capacity, map_send, (const uint4*)x, row_bytes / 16, (uint4*)wire, overflow);
   M3_LAUNCH_CHECK();
   return 0;
 }

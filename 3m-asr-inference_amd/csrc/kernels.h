@@ -98,9 +98,9 @@ int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_
 
 // ---- expert-parallel exchange bookkeeping on the device (ep_exchange.hip) ----
 int launch_ep_send_map(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
-                       int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream);
+                       int capacity, int32_t* map_send, void* wire, int row_bytes, hipStream_t stream, int32_t* overflow = nullptr);
 int launch_ep_send_rows(const int32_t* gate_idx, const int32_t* mapping, const int32_t* acc_hist, int S, int world, int e_loc,
-                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream);   // send map + scatter, one launch
+                        int capacity, int32_t* map_send, const void* x, void* wire, int row_bytes, hipStream_t stream, int32_t* overflow = nullptr);   // send map + scatter, one launch
 int launch_ep_recv_gate(const void* wire, int world, int e_loc, int capacity, int row_bytes, int32_t* gate_recv,
                         hipStream_t stream);
 

@@ -156,7 +156,12 @@ class ExpertParallelEncoder:
     transport that stages through the host (gloo with device tensors) or a failed capture falls back to eager enqueueing;
     ``self.graph_state`` says which ("engine graph" / "captured" / "eager: <reason>")."""
 
-    def __init__(self, engine, group=None, graph=True):
+    def __init__(self, engine, group=None, graph=True, capacity_factor=None):
+        """capacity_factor: None = every wire chunk can hold ALL rows of the largest rank (nothing can overflow; world x the bytes
+        a balanced routing needs).  A number f bounds the chunk at ceil(f x rows / world): the wire shrinks by world / f; a chunk
+        that would need more rows reports it on the device ("ep.overflow"), `forward` then repeats the forward with a capacity
+        that fits (all ranks agree through one MAX all-reduce per forward) -- rows are never dropped, unlike FastMoE's
+        capacity_factor (the reference's moe_conf default is -1: no dropping, ...domain_acc_hier.py:98-113)."""
         if not getattr(engine, "ep_stages", False):
             raise RuntimeError("ExpertParallelEncoder needs an engine with the expert-parallel stages (cfg.ep_world_size > 1, or "
                                "Engine(..., ep_stages=True) for a one-rank rehearsal)")
@@ -169,6 +174,8 @@ class ExpertParallelEncoder:
         self.graph_state = "eager: not bound"
         self._graph = None
         self._caps = {}
+        self.capacity_factor = None if capacity_factor is None else float(capacity_factor)
+        self.reruns = 0               # forwards repeated because a chunk overflowed its bounded capacity
 
     def on_host(self):
         return self.world > 1 and dist.get_backend(self.group) == "gloo"
@@ -180,7 +187,12 @@ class ExpertParallelEncoder:
         S = B * eng.output_shape(B, T)[1]
         key = (B, T)
         if key not in self._caps:
-            self._caps[key] = agree_capacity(S, eng.device, self.group)
+            full = agree_capacity(S, eng.device, self.group)
+            cap = full
+            if self.capacity_factor is not None and self.world > 1:
+                cap = min(full, -(-int(self.capacity_factor * full / self.world + 0.999) // 16) * 16)    # whole 16-row steps
+            self._caps[key] = max(1, cap)
+            self._full_cap = full
         eng.set_ep_capacity(self._caps[key])
         logits = eng.bind(feat, feat_len)
         names = eng.stage_names()
@@ -249,6 +261,16 @@ class ExpertParallelEncoder:
             self._enqueue_eager()
         return logits
 
+    def overflow_needed(self):
+        """After a forward (stream synchronised): 0, or the rows per chunk the largest chunk of any rank would have needed
+        (MAX over the ranks: the capacity is a shape every rank shares)."""
+        need = int(self.eng.buffer("ep.overflow", torch.int32)[0].item())
+        if self.world > 1:
+            t = torch.tensor([need], dtype=torch.int64, device="cpu" if self.on_host() else self.eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            need = int(t.item())
+        return need
+
     def host_syncs_per_forward(self):
         return 2 * self.eng.cfg.num_blocks if self.on_host() else 0
 
@@ -259,6 +281,16 @@ class ExpertParallelEncoder:
             self._bound_io = (feat, feat_len)
         logits = self.enqueue()
         self.eng.stream.synchronize()
+        if self.capacity_factor is not None:
+            need = self.overflow_needed()
+            while need > self._bound[3]:           # a chunk overflowed: this forward's result is invalid -> larger wire, again
+                B, T = int(feat.shape[0]), int(feat.shape[1])
+                self._caps[(B, T)] = min(self._full_cap, -(-int(need * 1.25) // 16) * 16)
+                self.reruns += 1
+                self.bind(feat, feat_len)
+                logits = self.enqueue()
+                self.eng.stream.synchronize()
+                need = self.overflow_needed()
         return logits
 
 
@@ -278,10 +310,12 @@ class InProcessRanks:
             if e.cfg.ep_world_size != self.world or e.cfg.ep_rank != r:
                 raise RuntimeError("engine %d was built for rank %d of %d" % (r, e.cfg.ep_rank, e.cfg.ep_world_size))
 
-    def forward(self, feats, feat_lens):
+    def forward(self, feats, feat_lens, capacity=None):
+        """capacity: rows per wire chunk (None = the largest row count of any rank: nothing can overflow).  After the call
+        ``self.overflow`` = rows the fullest chunk of any rank needed beyond a bounded capacity (0 = the result is valid)."""
         engs, W = self.engines, self.world
         rows = [int(f.shape[0]) * e.output_shape(int(f.shape[0]), int(f.shape[1]))[1] for e, f in zip(engs, feats)]
-        cap = max(rows)                                           # agree_capacity: the largest row count of any rank
+        cap = max(rows) if capacity is None else int(capacity)    # agree_capacity: the largest row count of any rank
         logits, wires, segs = [], [], None
         for e, f, l in zip(engs, feats, feat_lens):
             e.set_ep_capacity(cap)
@@ -308,4 +342,5 @@ class InProcessRanks:
                     for j in range(W):
                         wires[j][1][i].copy_(wires[i][0][j])
                 torch.cuda.synchronize()
+        self.overflow = max(int(e.buffer("ep.overflow", torch.int32)[0].item()) for e in engs)
         return logits

@@ -115,6 +115,8 @@ def parse():
                          "shortens one forward by 2.5 %% but eight concurrently active queues collapse the 4-context throughput)")
     ap.add_argument("--packed-rows", choices=["auto", "on", "off"], default="auto",
                     help="ragged batches: run the blocks on the packed valid frames (auto = for batch > 1)")
+    ap.add_argument("--ep-full-wire", action="store_true",
+                    help="--ep: every wire chunk holds ALL rows of the largest rank (the round-2/3 shape) instead of the bounded wire")
     ap.add_argument("--ep-probe-inject-failure", action="store_true",
                     help="diagnostic (tests): make the expert-parallel probe raise, to show that a failing probe is visible")
     return ap.parse_args()
@@ -228,8 +230,10 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
     cfg = EncoderConfig(num_blocks=L, num_experts=E // world, ep_world_size=world, ep_rank=rank, weight_dtype=wdt,
                         fp8_activations=fp8a)
     eng = Engine.from_state_dict(cfg, weights_full, device=dev, ep_stages=True)
-    ep = ExpertParallelEncoder(eng, graph=not args.no_graph)
-    ep.bind(feat, feat_len)
+    # bounded wire: chunks of 2 x (rows / world) instead of all rows; a chunk that overflows is reported on the device and the
+    # binding is redone with a capacity that fits BEFORE the timed region (rows are never dropped)
+    ep = ExpertParallelEncoder(eng, graph=not args.no_graph, capacity_factor=(None if args.ep_full_wire else 2.0))
+    ep.forward(feat, feat_len)
 
     def sync():
         torch.cuda.synchronize()
@@ -255,6 +259,8 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     _, S, D, cap = ep._bound
+    overflow_after = ep.overflow_needed() if not args.ep_full_wire else 0
+    routed_rows = int((torch.stack([eng.buffer("blocks.%d.gate_idx" % li, torch.int32) for li in range(L)]) >= 0).sum().item()) / max(L, 1)
     kern = {st["name"]: st["kernel"] for st in eng.stage_info()}
     touched = []
     for li in range(L):
@@ -264,6 +270,10 @@ def run_ep(args, rank, world, dev, dist, weights_full, steps, warmup, wdt, B, va
             "frames_per_step_all_ranks": int(frames_all.item()), "batch_per_gpu": B, "padded_frames": T,
             "experts_per_gpu": E // world, "weight_dtype": wdt, "rows_per_rank": S, "packed_rows": bool(B > 1 and eng.packed_rows()),
             "wire": {"capacity_rows": cap, "bytes_per_exchange_per_rank": int(world * (cap + 1) * D * 4), "wire_dtype": "f32",
+                     "needed_bytes_per_exchange_per_rank": int(routed_rows * D * 4),
+                     "capacity_policy": ("all rows per chunk (cannot overflow)" if args.ep_full_wire else
+                                         "2 x rows / world per chunk, repeated with a larger wire on overflow"),
+                     "forwards_repeated_for_overflow": ep.reruns, "overflow_after_timed_region": overflow_after,
                      "collectives_per_forward": 2 * L, "host_syncs_per_forward": ep.host_syncs_per_forward(),
                      "backend": (dist.get_backend() if world > 1 else "none (one rank: device copy)")},
             "forward_graph": ep.graph_state, "expert_kernel": kern.get("blocks.0.moe_ep.expert"),
@@ -585,7 +595,7 @@ def main():
         # correction of MI355X_MICROARCH.md (HBM).  null when no summary of this exact workload is committed.
         for r_ in (roofline, roofline_expert):
             r_["traffic"] = None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+        pmc = next((q_ for q_ in (os.path.join(ROOT, "profiles", r_ + "_pmc_bench.json") for r_ in ("r04", "r03")) if os.path.exists(q_)), "")
         if os.path.exists(pmc):
             try:
                 ent = json.load(open(pmc))
@@ -595,15 +605,17 @@ def main():
                         if k_:
                             n_l_ = float(sum(v["launches"] for v in k_))      # launch-weighted over the family's template variants
                             r_["traffic"] = int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in k_) / max(n_l_, 1.0))
-                            r_["traffic_source"] = "profiles/r03_pmc_bench.json (rocprofv3 --pmc over bench.py --pmc-safe, timed-workload launches only)"
+                            r_["traffic_source"] = "profiles/%s (rocprofv3 --pmc over bench.py --pmc-safe, timed-workload launches only)" % os.path.basename(pmc)
             except Exception:
                 pass
         # The same kernels' durations as rocprofv3 --kernel-trace --stats saw them over this command (the committed summary of the
         # workload: profiles/r03_kernel_stats*.csv).  `avg_launch_us` above is a HIP-event pair around each stage on the engine
         # stream, one forward alone: it contains the dispatch of the launch (~2-3 us); the profiler's figure is the kernel's own
         # begin -> end (at the bench's context count, i.e. under contention).  Both are reported; `frac` uses the larger, in-situ one.
-        kt_csv = {("f32", 1, 206, 18, 32): "r03_kernel_stats.csv", ("bf16", 16, 500, 18, 32): "r03_kernel_stats_cfg3.csv",
-                  ("fp8", 64, 500, 18, 64): "r03_kernel_stats_cfg5share.csv"}.get((cfg.weight_dtype, B, T, cfg.num_blocks, cfg.num_experts))
+        kt_csv = {("f32", 1, 206, 18, 32): "kernel_stats.csv", ("bf16", 16, 500, 18, 32): "kernel_stats_cfg3.csv",
+                  ("fp8", 64, 500, 18, 64): "kernel_stats_cfg5share.csv"}.get((cfg.weight_dtype, B, T, cfg.num_blocks, cfg.num_experts))
+        if kt_csv:      # the newest committed summary of this workload
+            kt_csv = next((r_ + "_" + kt_csv for r_ in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r_ + "_" + kt_csv))), None)
         if kt_csv and os.path.exists(os.path.join(ROOT, "profiles", kt_csv)):
             try:
                 import csv

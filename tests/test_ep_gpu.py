@@ -119,7 +119,7 @@ def test_ep_world1_bf16_equals_engine():
             assert not torch.equal(want16, want)        # (the two modes do differ: bf16 activation operands are in use)
 
 
-def _worker(rank, world, port, out_dir, wdt):
+def _worker(rank, world, port, out_dir, wdt, capacity_factor=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     e_loc = 2
@@ -131,7 +131,9 @@ def _worker(rank, world, port, out_dir, wdt):
     feat = torch.randn(2, T, cfg.input_dim, generator=g)
     fl = torch.tensor([[T, T - 20]], dtype=torch.int32)
     eng = Engine.from_state_dict(cfg, w, device="cuda:0")          # ep_world_size > 1 -> staged (unfused) route path; B = 2: packed rows
-    out = ExpertParallelEncoder(eng).forward(feat.cuda(), fl.cuda()).cpu()
+    ep = ExpertParallelEncoder(eng, capacity_factor=capacity_factor)
+    out = ep.forward(feat.cuda(), fl.cuda()).cpu()
+    np.save(os.path.join(out_dir, "reruns%d.npy" % rank), np.array([ep.reruns, ep._bound[3], ep._full_cap]))
     # reference: all experts local (fp32: the CPU oracle; bf16: the single-rank engine of the same precision, whose row
     # results are position independent)
     if wdt == "f32":
@@ -144,6 +146,22 @@ def _worker(rank, world, port, out_dir, wdt):
     np.save(os.path.join(out_dir, "err%d.npy" % rank), np.array([err, float(want[valid].abs().max())]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_ep_bounded_wire_repeats_on_overflow(tmp_path):
+    """capacity_factor bounds a wire chunk at f x rows / world instead of all rows; a chunk that needs more is reported on the
+    device and the forward is repeated with a capacity that fits -- no row is dropped (the fixed-shape wire moved
+    world x the bytes needed).  f = 0.3 at world 2 cannot hold a balanced routing: at least one repeat, same logits as ever."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "f32", 0.3), nprocs=2, join=True)
+    for r in range(2):
+        err, scale = np.load(os.path.join(str(tmp_path), "err%d.npy" % r))
+        reruns, cap, full = np.load(os.path.join(str(tmp_path), "reruns%d.npy" % r))
+        assert err <= 2e-4 + 1e-3 * scale, (r, err)
+        assert reruns >= 1 and cap <= full, (reruns, cap, full)
 
 
 @pytest.mark.parametrize("world,wdt", [(2, "f32"), (4, "f32"), (4, "bf16")])
@@ -221,6 +239,24 @@ def test_ep_world8_real_dims_one_process(mode):
     # dependence on its CU's other residents was found -- DESIGN.md 10.8)
     again = ranks.forward(feats, lens)
     assert all(torch.equal(a, b) for a, b in zip(outs, again)), "two runs of the same expert-parallel forward differ"
+    # bounded wire: chunks of 2 x rows / world instead of all rows.  These synthetic routers are far from balanced
+    # (raw random router weights send most frames of an utterance to a few experts), so the first try may overflow: the device
+    # reports the rows the fullest chunk needed, the forward is repeated with that capacity (what ExpertParallelEncoder.forward
+    # does) and must then be clean; in fp8 arithmetic (a row's result does not depend on how rows are grouped) with the same
+    # bits as the full wire.  (bf16: the receive side's row count picks another form of the grouped FFN: no bit comparison.)
+    full_cap = max(int(f.shape[0]) * e.output_shape(int(f.shape[0]), int(f.shape[1]))[1] for e, f in zip(engines, feats))
+    cap = -(-2 * full_cap // world // 16) * 16
+    bounded = [o.clone() for o in ranks.forward(feats, lens, capacity=cap)]
+    if ranks.overflow > cap:
+        cap = min(full_cap, -(-ranks.overflow // 16) * 16)
+        bounded = [o.clone() for o in ranks.forward(feats, lens, capacity=cap)]
+    assert ranks.overflow == 0
+    print("bounded wire: %d rows per chunk (full wire %d)" % (cap, full_cap))
+    if fp8:
+        assert all(torch.equal(a, b) for a, b in zip(outs, bounded))
+    ranks.forward(feats, lens, capacity=16)
+    assert ranks.overflow > 16
+    ranks.forward(feats, lens)                 # (back to the full wire for the checks below)
     ek = {s_["name"]: s_["kernel"] for s_ in engines[0].stage_info()}["blocks.0.moe_ep.expert"]
     if fp8:
         assert ek == "expert_ffn_fused_fp8_kernel", ek
