@@ -970,6 +970,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
   if (int rc = init_gemm_f32_tiled_kernels()) return rc;
   if (int rc = init_gemm_bf16_dma_kernels()) return rc;
+  if (int rc = init_expert_gemm_g256_kernels()) return rc;
   if (int rc = init_moe_router_kernels()) return rc;
   if (int rc = init_relpos_attention_bf16_kernels()) return rc;
   Plan pl = make_plan(c, workspace, B, T, e->ep_capacity);

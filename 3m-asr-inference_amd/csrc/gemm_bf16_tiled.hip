@@ -501,6 +501,13 @@ int launch_expert_ffn_bf16w_tiled(const float* x, int ldx, const int32_t* pos, c
                                   int F, const void* w1, const float* b1, const void* w2, int w2_sliced, void* hbuf,
                                   float* ybuf, hipStream_t stream, const float* b2, float* y_scatter) {
   M3_REQUIRE((D & 127) == 0 && (F & 127) == 0, "expert_ffn tiled: idim=%d / hidden=%d must be multiples of 128", D, F);
+  if (y_scatter == nullptr && expert_ffn_bf16_g256(S, E, D, F)) {
+    // saturating row counts: 256 x 256 x 64 LDS-DMA tiles (expert_gemm_g256.hip).  Its A operand is bf16 in memory: the rows are
+    // converted once (behind ybuf in the slab region: S * D * 2 bytes of its F / 64 * S * D * 4) and gathered by the fills
+    void* xb = (char*)ybuf + align_up((size_t)S * D * 4, 256);
+    if (int rc = launch_rows_to_bf16(x, ldx, S, D, xb, stream)) return rc;
+    return launch_expert_ffn_bf16_g256(xb, D, pos, acc_hist, S, E, D, F, w1, b1, w2, w2_sliced, hbuf, ybuf, stream);
+  }
   if (int rc = init_gemm_bf16_tiled_kernels()) return rc;
   // rows per expert ~ S/E: small tiles (4x the workgroups, half the k-steps) until an expert fills 128-row tiles
   const bool big = S / E >= 192;

@@ -169,6 +169,13 @@ int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, co
                                 int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, const float* b2,
                                 float* slab, int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
                                 hipStream_t stream);
+// grouped bf16 expert GEMMs on 256 x 256 x 64 LDS-DMA tiles (expert_gemm_g256.hip): saturating row counts (>= 512 rows per expert)
+bool expert_ffn_bf16_g256(int S, int E, int D, int F);
+int init_expert_gemm_g256_kernels();
+int launch_rows_to_bf16(const float* x, int ldx, int S, int D, void* xb, hipStream_t stream);
+int launch_expert_ffn_bf16_g256(const void* xb, int ldxb, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
+                                const void* w1, const float* b1, const void* w2, int w2_sliced, void* hbuf, float* ybuf,
+                                hipStream_t stream);
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,

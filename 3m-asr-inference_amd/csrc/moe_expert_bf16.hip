@@ -186,11 +186,14 @@ int expert_ffn_w16_slices(int wmode, int S, int E, int D, int F) {
   return w16_fused(wmode, S, E, D, F) ? w16_fsplit(wmode, S, E, D, F) : expert_ffn_bf16_slices(S, E, D, F);
 }
 int expert_ffn_w16_launches(int wmode, int S, int E, int D, int F) {
-  return w16_fused(wmode, S, E, D, F) ? 1 : (expert_ffn_bf16_tiled(S, E, D, F) ? 2 : 1);
+  if (w16_fused(wmode, S, E, D, F)) return 1;
+  if (wmode == 1 && expert_ffn_bf16_tiled(S, E, D, F) && expert_ffn_bf16_g256(S, E, D, F)) return 3;   // rows -> bf16, GEMM-1, GEMM-2
+  return expert_ffn_bf16_tiled(S, E, D, F) ? 2 : 1;
 }
 const char* expert_ffn_w16_kernel(int wmode, int S, int E, int D, int F) {
   if (w16_fused(wmode, S, E, D, F)) return "expert_ffn_fused_fp8_kernel";
   if (wmode == 3) wmode = 2;
+  if (wmode == 1 && expert_ffn_bf16_tiled(S, E, D, F) && expert_ffn_bf16_g256(S, E, D, F)) return "expert_gemm_g256_kernel";
   if (expert_ffn_bf16_tiled(S, E, D, F)) return wmode == 2 ? "gemm_bf16w_tiled_kernel<grouped,fp8>" : "gemm_bf16w_tiled_kernel<grouped>";
   return wmode == 2 ? "expert_ffn_w8_kernel" : "expert_ffn_bf16w_kernel";
 }

@@ -107,7 +107,11 @@ def test_linear_bf16_folded_layernorm(M, mean, std):
                                            # rows), 64 experts, F not a multiple of 128
                                            (4096, 32, 512, 1024, "skewed"), (16384, 32, 512, 1024, "uniform"),
                                            (33000, 32, 512, 1024, "with_dropped"), (9000, 64, 512, 1024, "uniform"),
-                                           (5000, 16, 512, 1088, "skewed")])
+                                           (5000, 16, 512, 1088, "skewed"),
+                                           # >= 512 rows per expert: the 256 x 256 x 64 LDS-DMA tiles of expert_gemm_g256.hip
+                                           # (16384 / 33000 / 6500 above as well): skew with empty and one-row experts, dropped rows
+                                           (40000, 32, 512, 1024, "skewed"), (20000, 8, 512, 1024, "skewed"),
+                                           (70000, 64, 512, 1024, "with_dropped")])
 def test_fmoe_expert_bf16(S, E, D, Fh, mode):
     rng = np.random.default_rng(S + E)
     if mode == "skewed":
