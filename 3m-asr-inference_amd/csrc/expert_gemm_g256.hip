@@ -46,6 +46,9 @@ constexpr int kGLds = kGStages * kGStage + 32 * 1024; // 4-stage ring (128 KB) +
 #ifndef G256_RUN
 #define G256_RUN 8
 #endif
+#ifndef G256_LATE_READS
+#define G256_LATE_READS 3
+#endif
 constexpr int kGRun = G256_RUN;
 
 __device__ __forceinline__ void g_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -91,6 +94,8 @@ __global__ __launch_bounds__(512, 1) void expert_gemm_g256_kernel(const G256Para
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
+  // (waves w and w + 4 of a work-group share a SIMD: with the rows taken as wave & 1 instead -- the same-row waves paired on a
+  //  SIMD -- the kernel is 7-9 % slower, 124 / 94 us against 116 / 86)
   const int wm = wave >> 2, wn = wave & 3;
   const int nsteps = p.K / GBK;
 
@@ -160,21 +165,34 @@ __global__ __launch_bounds__(512, 1) void expert_gemm_g256_kernel(const G256Para
   const int frag_off = col * 64 + 16 * (kq ^ (((col >> 3) & 1) << 1));
   f32x4 acc[MT][NT];
   bf16x8 fa[2][MT], fb[2][NT];
-  auto read_frags = [&](int buf, int set) {
+  // The 12 fragment reads of a stage are split over the two phases so that PREP (4 fill issues ~ 366 cycles + reads) and MATH
+  // (32 MFMAs ~ 519 cycles + reads) take about the same time: kLateReads of the A fragments (the last ones the MFMAs need) are
+  // read in MATH, between the MFMAs of the previous stage; the rest in PREP.
+  constexpr int kLateReads = G256_LATE_READS;
+  auto read_frags = [&](int buf, int set) {        // PREP part (or everything, for a tile's first stage: late = false)
     const unsigned char* a_lds = g_lds + buf * kGStage + (128 * wm) * 64 + frag_off;
     const unsigned char* b_lds = g_lds + buf * kGStage + kGOp + (64 * wn) * 64 + frag_off;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const bf16x8*>(b_lds + 16 * nt * 64);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lds + 16 * mt * 64);
+    for (int mt = 0; mt < MT - kLateReads; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lds + 16 * mt * 64);
   };
-  auto multiply = [&](int set) {
+  auto read_frags_late = [&](int buf, int set) {
+    const unsigned char* a_lds = g_lds + buf * kGStage + (128 * wm) * 64 + frag_off;
+#pragma unroll
+    for (int mt = MT - kLateReads; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(a_lds + 16 * mt * 64);
+  };
+  // MFMAs of stage `set`; late_buf >= 0: the late fragment reads of the NEXT stage (buffer late_buf, the other set) go out after
+  // the first MFMAs (their registers were last used by the MFMAs of the stage before this one: free)
+  auto multiply = [&](int set, int late_buf) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt == 1 && late_buf >= 0) read_frags_late(late_buf, set ^ 1);
       // TRANSPOSED product: the W fragment is the MFMA's A operand -> this lane holds out[row 16 mt + col][cols 16 nt + 4 kq ..+3]
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16h(fb[set][nt], fa[set][mt], acc[mt][nt]);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -223,6 +241,7 @@ __global__ __launch_bounds__(512, 1) void expert_gemm_g256_kernel(const G256Para
     G_DIAG(dg[4] += __builtin_amdgcn_s_memtime() - dg[1]; dg[1] = __builtin_amdgcn_s_memtime();)
     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");       // stages 0 and 1 of this tile landed (all waves)
     read_frags(0, 0);
+    read_frags_late(0, 0);
     G_DIAG(dg[2] += __builtin_amdgcn_s_memtime() - dg[1]; dg[1] = __builtin_amdgcn_s_memtime();)
     if (wm == 1) asm volatile("s_barrier" ::: "memory");                  // row 1 runs one phase behind
     // (the fragment set is a COMPILE-TIME constant at every use -- a run-time index would put the fragment arrays in scratch --
@@ -245,9 +264,11 @@ __global__ __launch_bounds__(512, 1) void expert_gemm_g256_kernel(const G256Para
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       G_DIAG(dg[12] += __builtin_amdgcn_s_memtime() - tt_; tt_ = __builtin_amdgcn_s_memtime();)
       __builtin_amdgcn_sched_barrier(0);
-      multiply(SET);
+      multiply(SET, s + 1 < nsteps ? (s + 1) % kGStages : -1);
       G_DIAG(asm volatile("s_nop 0" ::: "memory"); dg[13] += __builtin_amdgcn_s_memtime() - tt_; tt_ = __builtin_amdgcn_s_memtime();)
-      asm volatile("s_barrier" ::: "memory");
+      // (the late fragment reads were issued ~30 MFMAs ago: returned long since; the wait makes "every read of this phase is done
+      //  before the barrier" formal, which is what the ring's reuse argument rests on)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       G_DIAG(dg[14] += __builtin_amdgcn_s_memtime() - tt_;)
     };
     for (int s = 0; s < nsteps; s += 2) {
