@@ -50,6 +50,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
   constexpr int C_LD = TBN + 4;                     // fp32 elements per row of the epilogue image
   constexpr int MT = TBM / 32, NT = TBN / 32;       // 16x16 MFMA tiles per wave (wave tile = TBM/2 x TBN/2)
   constexpr bool A16 = GRP == 2 || A16IN;           // A operand already bf16 (16-B chunks of 8 elements)
+#ifdef M3_NO_EARLY_EPI                              // (A/B builds only)
+  constexpr bool EARLY_EPI = false;
+#else
+  constexpr bool EARLY_EPI = TBM <= 64 && GRP == 0; // epilogue operands requested before the k loop (see below)
+#endif
   constexpr int CA = A16 ? TBK / 8 : TBK / 4, RA = 256 / CA, JA = TBM / RA;   // A staging: chunks per row, rows per pass, passes
   constexpr int WCE = W8 ? 16 : 8, WSZ = W8 ? 1 : 2;          // W elements per 16-B chunk, bytes per element
   constexpr int CB = TBK / WCE, RB = 256 / CB, JB = TBN / RB;  // W staging: 16-B chunks per row, rows per pass, passes
@@ -184,6 +189,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
 #pragma unroll
   for (int j = 0; j < JA; ++j) s1[j] = s2[j] = 0.f;
 
+  // ---- fp32 epilogue, row-wise: a lane owns 4 consecutive output columns, a wave sweeps rows ----
+  constexpr int LPR = OUTW / 4;                     // lanes per output row (32, GLU 16)
+  constexpr int RPI = 64 / LPR;                     // rows per wave iteration (2, GLU 4)
+  const int c4 = 4 * (lane % LPR);                  // first of this lane's 4 columns inside the tile
+  const int n = n0 + c4;
+  float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4], wsc[4];
+  const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
+  // Every load of the sweep is issued BEFORE it (residual rows into registers -- the accumulators are dead --, the row
+  // masks resolved here): a load inside the sweep makes hipcc wait vmcnt(0) in every iteration, and vmcnt counts the
+  // previous iteration's stores too, so each iteration paid a full store round trip (in-kernel stamps of the LDS-DMA
+  // kernel, tools/diag_gemm_dma.py: the sweep was the longest phase of the work-group).
+  // EARLY_EPI (64-row tiles: 8 residual float4 per lane): the same operands are requested BEFORE the k loop -- after it they
+  // were one more exposed round trip (~1.5 us of an ~11 us launch at configs[2]'s 1984 rows)
+  constexpr int IT = TBM / (4 * RPI);
+  f32x4 res_all[IT];
+  bool pad_all[IT];
+  int mo_all[IT];                                   // output row (grouped GEMM-2 with p.y_rows: the row's place in another order)
+  auto fetch_epilogue_operands = [&]() {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ne = min(n + e, Nout - 1);
+    wsc[e] = W8 ? p.w_scale[(size_t)expert * p.N + ne] : 1.f;
+    bias0[e] = p.bias ? p.bias[(GRP ? (size_t)expert * p.N : 0) + ne] : 0.f;
+    bias1[e] = (GLU && p.bias) ? p.bias[ne + Nout] : 0.f;
+    wsum0[e] = LN ? p.ln_wsum[ne] : 0.f;
+    wsum1[e] = (LN && GLU) ? p.ln_wsum[ne + Nout] : 0.f;
+    wbeta0[e] = (LN && p.mask_in) ? p.ln_wbeta[ne] : 0.f;
+    wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, m_end - 1);      // clamped, never branched around
+    mo_all[it] = (GRP == 2 && p.y_rows != nullptr) ? p.y_rows[m] : m0 + (4 * it + wave) * RPI + lane / LPR;
+    res_all[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.resid) {
+      if (vec_ok) {
+        res_all[it] = ldg4(p.resid + (size_t)m * p.ldr + n);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res_all[it][e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
+      }
+    }
+    pad_all[it] = (p.mask_in || p.mask_out) ? ((m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch]) : false;
+  }
+  };
+
   const int nsteps = p.K / TBK;
   f32x4 areg[JA];                                   // A16: the 16 bytes are 8 bf16, carried as they are
   u32x4 breg[JB];                                   // 16 bytes of W: 8 bf16, or 16 fp8 (W8)
@@ -254,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     }
   };
   load_tiles(0);
+  if constexpr (EARLY_EPI) fetch_epilogue_operands();   // behind the first tiles in the (in-order) return queue
   store_tiles(0, 1.f);
   __syncthreads();
 
@@ -297,47 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       for (int r = 0; r < 4; ++r) Cs[((TBM / 2) * wm + 16 * mt + 4 * kq + r) * C_LD + btile(nt) + col] = acc[mt][nt][r];
   __syncthreads();
 
-  // ---- fp32 epilogue, row-wise: a lane owns 4 consecutive output columns, a wave sweeps rows ----
-  constexpr int LPR = OUTW / 4;                     // lanes per output row (32, GLU 16)
-  constexpr int RPI = 64 / LPR;                     // rows per wave iteration (2, GLU 4)
-  const int c4 = 4 * (lane % LPR);                  // first of this lane's 4 columns inside the tile
-  const int n = n0 + c4;
-  float bias0[4], bias1[4], wsum0[4], wsum1[4], wbeta0[4], wbeta1[4], wsc[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int ne = min(n + e, Nout - 1);
-    wsc[e] = W8 ? p.w_scale[(size_t)expert * p.N + ne] : 1.f;
-    bias0[e] = p.bias ? p.bias[(GRP ? (size_t)expert * p.N : 0) + ne] : 0.f;
-    bias1[e] = (GLU && p.bias) ? p.bias[ne + Nout] : 0.f;
-    wsum0[e] = LN ? p.ln_wsum[ne] : 0.f;
-    wsum1[e] = (LN && GLU) ? p.ln_wsum[ne + Nout] : 0.f;
-    wbeta0[e] = (LN && p.mask_in) ? p.ln_wbeta[ne] : 0.f;
-    wbeta1[e] = (LN && GLU && p.mask_in) ? p.ln_wbeta[ne + Nout] : 0.f;
-  }
-  const bool vec_ok = ((p.ldy & 3) == 0) && (!p.resid || (p.ldr & 3) == 0) && (n + 3 < Nout);
-  // Every load of the sweep is issued BEFORE it (residual rows into registers -- the accumulators are dead --, the row
-  // masks resolved here): a load inside the sweep makes hipcc wait vmcnt(0) in every iteration, and vmcnt counts the
-  // previous iteration's stores too, so each iteration paid a full store round trip (in-kernel stamps of the LDS-DMA
-  // kernel, tools/diag_gemm_dma.py: the sweep was the longest phase of the work-group).
-  constexpr int IT = TBM / (4 * RPI);
-  f32x4 res_all[IT];
-  bool pad_all[IT];
-  int mo_all[IT];                                   // output row (grouped GEMM-2 with p.y_rows: the row's place in another order)
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int m = min(m0 + (4 * it + wave) * RPI + lane / LPR, m_end - 1);      // clamped, never branched around
-    mo_all[it] = (GRP == 2 && p.y_rows != nullptr) ? p.y_rows[m] : m0 + (4 * it + wave) * RPI + lane / LPR;
-    res_all[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.resid) {
-      if (vec_ok) {
-        res_all[it] = ldg4(p.resid + (size_t)m * p.ldr + n);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) res_all[it][e] = p.resid[(size_t)m * p.ldr + min(n + e, Nout - 1)];
-      }
-    }
-    pad_all[it] = (p.mask_in || p.mask_out) ? ((m % p.rows_per_batch) >= p.row_len[m / p.rows_per_batch]) : false;
-  }
+  if constexpr (!EARLY_EPI) fetch_epilogue_operands();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int row = (4 * it + wave) * RPI + lane / LPR;

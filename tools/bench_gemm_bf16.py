@@ -1,5 +1,5 @@
 """Micro-benchmark of the bf16-weight GEMM kernels at long-batch shapes (HIP events, L2-warm).
-usage: python tools/bench_gemm_bf16.py [M ...] [--a16]
+usage: python tools/bench_gemm_bf16.py [M ...] [--a16] [--shapes NxK,NxK,...]
   --a16: A given as bf16 (the engine's bf16 activation copies): from 512 rows on this is the LDS-DMA kernel
   (M3_DMA_MIN_ROWS=<rows> moves that threshold; M3_TILED_MIN_ROWS=<rows>: huge = K-split kernel only)"""
 import sys, os
@@ -9,7 +9,10 @@ from m3asr import ops, _lib
 
 a16 = "--a16" in sys.argv
 Ms = [int(v) for v in sys.argv[1:] if v.isdigit()] or [1984]
+custom = [v.split("=", 1)[1] if "=" in v else sys.argv[i + 1] for i, v in enumerate(sys.argv) if v.startswith("--shapes")]
 shapes = [("qkv", 1536, 512), ("w1", 1024, 512), ("w2", 512, 1024), ("out", 512, 512), ("w1x2", 2048, 1024), ("logits", 1434, 512)]
+if custom:
+    shapes = [("NxK", int(t.split("x")[0]), int(t.split("x")[1])) for t in custom[0].split(",")]
 for M in Ms:
     for name, N, K in shapes:
         a = torch.randn(M, K, device="cuda")
