@@ -111,9 +111,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
       if (e == p.grp_E) return;
       expert = e;
     }
-  } else if (m_tile >= p.m_tiles || (p.m_dev != nullptr && m0 > *p.m_dev)) {
-    return;                                         // padding of the last group of 8 row tiles / no live row (packed batch)
+  } else if (m_tile >= p.m_tiles) {
+    return;                                         // padding of the last group of 8 row tiles
   }
+  // packed ragged batch: the live-row count is a device value.  Its load is requested here and looked at BEHIND the first tiles'
+  // loads (rows up to p.M exist, so those are safe to request): in front of them it was one more dependent round trip per launch
+  int m_live = 0x7fffffff;
+  if (GRP == 0 && p.m_dev != nullptr) m_live = *p.m_dev;
   if (CONV && p.conv_len != nullptr) {
     const int per_utt = p.conv_T2 * p.conv_F2;
     const int b0 = m0 / per_utt, b1 = min(m0 + TBM - 1, p.M - 1) / per_utt;
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_tiled_kernel(const GemmPara
     }
   };
   load_tiles(0);
+  if (GRP == 0 && m0 > m_live) return;             // no live row in this tile (whole work-group; the requested loads are dropped)
   if constexpr (EARLY_EPI) fetch_epilogue_operands();   // behind the first tiles in the (in-order) return queue
   store_tiles(0, 1.f);
   __syncthreads();
