@@ -278,6 +278,7 @@ struct Plan {
   int32_t* lens;
   float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
   void* xb;                             // bf16 copy of the residual stream (16-bit modes, long batches)
+  unsigned char* xq; float* xq_scale;   // fp8 plans: the MoE input rows as e4m3 [S][D] + per-row scales (router kernel -> fused fp8 expert kernel)
   float* xstats;                        // [S][kXbStatParts][2]: row statistics of xb for the folded-LayerNorm GEMMs (gemm_bf16_dma.hip)
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
   void* moe_ws; size_t moe_ws_bytes;
@@ -330,6 +331,11 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   p.glu = cv.take<float>((size_t)S * D);
   p.dw = cv.take<float>((size_t)S * D);
   p.xn = cv.take<float>((size_t)S * D);
+  p.xq = nullptr; p.xq_scale = nullptr;
+  if (c.weight_dtype == M3_FP8 && D == 512) {
+    p.xq = cv.take<unsigned char>((size_t)S * D);
+    p.xq_scale = cv.take<float>((size_t)S);
+  }
   p.rl = cv.take<float>((size_t)S * Etot);
   p.eall = cv.take<float>((size_t)S * Etot * c.num_blocks);
   p.gate_idx = cv.take<int32_t>((size_t)c.num_blocks * S);
@@ -669,6 +675,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     // norm_ff while it gathers rows, so xn is never materialised
     const bool split_route = c.fuse_route == 2 && world == 1 && S < 1024 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
     bool router_gate = false;   // the dedicated router kernel also did SoftmaxTopK (no moe_top1 stage)
+    bool use_xq = false;        // ... and left the rows quantised for the fused fp8 expert kernel
     if (split_route) {
       GemmParams r;
       r.A = x; r.lda = D; r.W = w.router_x.w; r.bias = w.router_x.b; r.ln_wsum = w.router_x.wsum; r.ln_eps = eps;
@@ -709,10 +716,17 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     if (moe_router_supports(De, D, Etot) && S >= router_min_rows) {
       // the dedicated kernel: one work-group per 16 rows and all experts, every activation byte read once (moe_router.hip)
       const float* emb = pl.emb; const float* rw = w.router.w; const float* rb = w.router.b;
+      // fp8 arithmetic, all experts local, the fused expert kernel next: the rows leave the router kernel quantised (e4m3 + a scale
+      // per row) and the fp32 copy is not written at all (nothing else reads xn; debug taps keep it).  M3_ROUTER_XQ=0: as before
+      static const int xq_on = [] { const char* ev = getenv("M3_ROUTER_XQ"); return ev ? atoi(ev) : 1; }();
+      use_xq = xq_on && pl.xq != nullptr && world == 1 && c.ep_stages <= 0 && c.weight_dtype == M3_FP8 && w.h_scale > 0.f &&
+               expert_ffn_w8a8_fused(S, E, D, F);     // (the form launch_expert_ffn_w8a8 will take)
+      unsigned char* xq = use_xq ? pl.xq : nullptr; float* xqs = use_xq ? pl.xq_scale : nullptr;
+      float* xn_out = (use_xq && !c.debug_taps) ? nullptr : xn;
       add_stage(e, pfx + "moe_router", 1, [=](hipStream_t s) {
         // (+ SoftmaxTopK in its tail when the row-parallel top-1 launch would follow: gate_idx / gate_value come from here)
-        return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn, D, rl, Etot, S, Etot, pdev, s,
-                                 router_gate ? gidx : nullptr, router_gate ? gval : nullptr, live_len, live_rpb);
+        return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn_out, D, rl, Etot, S, Etot, pdev, s,
+                                 router_gate ? gidx : nullptr, router_gate ? gval : nullptr, live_len, live_rpb, xq, xqs);
       }, stage_info("moe_router_kernel", 1, (double)Etot * (De + D) * 4 + (double)S * (De + 2 * D + Etot) * 4, 2.0 * S * Etot * (De + D)));
     } else {
       add_gemm(e, pfx + "moe_router", r, true);
@@ -815,7 +829,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int wmode = e8 ? (h_scale > 0.f ? 3 : 2) : (e16 ? 1 : 0);
     const int elaunches = e16 ? expert_ffn_w16_launches(wmode, S, E, D, F) : (expert_ffn_f32_tiled(S, E, D, F) ? 2 : 1);
     add_stage(e, pfx + "moe_local.expert", elaunches, [=](hipStream_t s) {
-      if (e8) return launch_expert_ffn_w8a8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, mw.slab, s);
+      if (e8) return launch_expert_ffn_w8a8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, mw.slab, s,
+                                            use_xq ? pl.xq : nullptr, use_xq ? pl.xq_scale : nullptr);
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     }, stage_info(e16 ? expert_ffn_w16_kernel(wmode, S, E, D, F)
@@ -1162,6 +1177,10 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
   e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
+  if (pl.xq != nullptr) {
+    e->cur.buffers["xq"] = Buf{pl.xq, (size_t)S * D};
+    e->cur.buffers["xq_scale"] = Buf{pl.xq_scale, (size_t)S * 4};
+  }
   e->cur.buffers["embed"] = Buf{pl.emb, (size_t)S * De * 4};
   if (e->cur.a16) e->cur.buffers["xb"] = Buf{pl.xb, (size_t)S * D * 2};
   e->cur.buffers["lens"] = Buf{pl.lens, (size_t)B * 4};

@@ -92,7 +92,7 @@ int init_moe_router_kernels();
 int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx, int D, const float* W, const float* bias,
                       const float* gamma, const float* beta, float eps, float* xn, int ldxn, float* Y, int ldy, int M, int N,
                       const int32_t* m_dev, hipStream_t stream, int32_t* gate_idx = nullptr, float* gate_val = nullptr,
-                      const int32_t* row_len = nullptr, int rows_per_batch = 0);
+                      const int32_t* row_len = nullptr, int rows_per_batch = 0, void* xq = nullptr, float* xq_scale = nullptr);
 int launch_local_scatter(const void* x, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 int launch_local_gather(const void* buf, const int32_t* mapping, int S, int row_bytes, void* out, hipStream_t stream);
 
@@ -151,11 +151,12 @@ int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F);
 int init_expert_ffn_fused_fp8_kernels();
 int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                                float h_scale, float* ybuf, hipStream_t stream);
+                                float h_scale, float* ybuf, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr);
 // fp8 weights, dispatcher: h_scale > 0 asks for fp8 activations (taken where the fused kernel applies)
+bool expert_ffn_w8a8_fused(int S, int E, int D, int F);   // ... i.e. when this holds (moe_expert_bf16.hip)
 int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                            const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                           float h_scale, float* slab, hipStream_t stream);
+                           float h_scale, float* slab, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr);
 // long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
 // b2 / y_scatter (optional): GEMM-2 adds the expert's b2 and writes row i of the sorted order to row pos[i] of y_scatter
 // (the un-permute of the expert-parallel receive side, folded into the epilogue)

@@ -44,6 +44,10 @@ __device__ unsigned long long g_fused8_dbg[4096 * 8];
 #define M3_DIAG(...)
 #endif
 
+#ifdef M3_XQ_SELFTEST
+__device__ int g_xq_var;
+#endif
+
 namespace {
 
 constexpr int kTok = 128;            // tokens per work-group (4 waves x 32)
@@ -203,12 +207,15 @@ constexpr int kImgRow = 528;
 constexpr int kOffRaw = kOffImg + 4 * 32 * kImgRow;
 constexpr int kLdsBytes = kOffRaw + 4 * 4096;
 
-template <int FSPLIT>
+// XQ: the input rows arrive ALREADY quantised (e4m3 [S][512] + one fp32 scale per row, written by moe_router_kernel with the
+// arithmetic of quant_row below): a tile's X is 64 KB instead of 256 KB of fp32 rows and nothing is converted here.  With one
+// work item per work-group (configs[4]'s share: ~140 items on 256 CUs) the 256-KB prologue was 20 k of an item's ~90 k cycles.
+template <int FSPLIT, bool XQ = false>
 __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const float* __restrict__ x, int ldx, const int32_t* __restrict__ pos, const int32_t* __restrict__ acc_hist, int S, int E,
     int F, const unsigned char* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ b1,
     const unsigned char* __restrict__ w2, const float* __restrict__ s2, int w2_row_stride, int w2_slice_stride, float h_scale,
-    float* __restrict__ ybuf) {
+    float* __restrict__ ybuf, const unsigned char* __restrict__ xq_in, const float* __restrict__ xq_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -297,7 +304,47 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
       xq[2 * m + 1] = (long)(((unsigned long long)t[3] << 32) | t[2]);
     }
   };
-  {
+  if constexpr (XQ) {
+    const int my_src = pos[min(tile_row0 + r, row_end - 1)];
+    sx = xq_scale[my_src];
+    // two rows per instruction (lanes 0-31 / 32-63: 16 B each of a 512-B row), all 16 instructions in flight, straight into the image
+    u32x4 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int src = __shfl(my_src, 2 * i + h, 64);
+      t[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xq_in + (size_t)src * kD + 16 * r));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x4*>(img + (2 * i + h) * kImgRow + 16 * r) = t[i];
+#ifdef M3_XQ_SELFTEST   // debug: g_xq_var bit 0: image from the fp32 rows (old code), bit 1: sx from the fp32 rows
+    {
+      const int var = g_xq_var;
+      if (var) {
+        float sx_old = 1.f;
+        for (int i = 0; i < 32; ++i) {
+          const float* xr = x + (size_t)__shfl(my_src, i, 64) * ldx + 4 * lane;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 256);
+          float amax = 0.f;
+          for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+          amax = fmaxf(wave_max(amax), 1e-30f);
+          const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
+          if (r == i) sx_old = amax * (1.f / 448.f);
+          int q0 = 0, q1 = 0;
+          q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
+          q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
+          q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0] * inv, v1[1] * inv, q1, false);
+          q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2] * inv, v1[3] * inv, q1, true);
+          if (var & 1) {
+            *reinterpret_cast<int*>(img + i * kImgRow + 4 * lane) = q0;
+            *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * lane) = q1;
+          }
+        }
+        if (var & 2) sx = sx_old;
+      }
+    }
+#endif
+    read_xq();
+  } else {
     const int my_src = pos[min(tile_row0 + r, row_end - 1)];          // source row of token r (lanes r and r + 32 agree)
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {                                    // 8 rows per batch: 16 loads in flight per lane
@@ -323,26 +370,35 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
 
   // ---- the NEXT tile's X arrives under this tile's MFMAs: two rows per step by LDS-DMA into the raw rows (no registers
   //      held across the latency; 8 KB per CU in flight, below the LDS-DMA limit), quantised one step later ----
-  const unsigned long long xaddr = (unsigned long long)x;
+  const unsigned long long xaddr = XQ ? (unsigned long long)xq_in : (unsigned long long)x;
   const u32x4 rsx = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)((xaddr >> 32) & 0xffffu)),
-                     ((unsigned)(S - 1) * (unsigned)ldx + kD) * 4u, 0x00020000u};
+                     XQ ? (unsigned)S * (unsigned)kD : ((unsigned)(S - 1) * (unsigned)ldx + kD) * 4u, 0x00020000u};
   const unsigned raw_lds = (unsigned)__builtin_amdgcn_readfirstlane(
       (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)rawb);
   int my_src_n = 0;
   auto x_issue = [&](int i) {                           // row i of the next tile -> raw row i & 1
-    const unsigned soff = (unsigned)__builtin_amdgcn_readlane(my_src_n, i) * (unsigned)ldx * 4u;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readlane(my_src_n, i) * (XQ ? (unsigned)kD : (unsigned)ldx * 4u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of the raw row's previous occupant have returned
     const unsigned dst = raw_lds + (unsigned)(i & 1) * 2048u;
+    if constexpr (XQ) {
+      // a quantised row is 512 B: both halves of the wave fetch it (lanes l and l + 32 the same 16 B), and the fill is issued
+      // TWICE so that the counted waits of the step schedule (two fills per row) hold unchanged; 3 of the 4 copies come out of L2
+      const unsigned voff = (unsigned)(olane() & 31) * 16u;
+      dma16_hidden(rsx, voff, soff, dst);
+      dma16_hidden(rsx, voff, soff, dst + 1024u);
+    } else {
     const unsigned voff = (unsigned)olane() * 16u;
     dma16_hidden(rsx, voff, soff, dst);                   // (asm volatile + memory clobber: no load is moved across the
     dma16_hidden(rsx, voff + 1024u, soff, dst + 1024u);   // fills; the counted waits rely on the issue order)
+    }
   };
   // quantisation of an arrived row in two parts, each with ONE LDS round trip (the wave stalls on every lgkmcnt wait -- it is
   // the only wave of its SIMD): part 1 reads the row and keeps only its partial amax, part 2 (a service later) reduces it over
   // the wave without the LDS pipe, re-reads the row and converts it
   float x_amax = 0.f;
   auto x_quant1 = [&](int i) {                          // (after the wait for row i's two fills)
+    if constexpr (XQ) return;
     const char* src = rawb + (i & 1) * 2048 + olane() * 16;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
@@ -355,12 +411,17 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   };
   float x_inv = 0.f;
   auto x_quant2a = [&](int i) {                          // reduce over the wave, scale
+    if constexpr (XQ) return;
     const float amax = fmaxf(wave_amax_dpp(x_amax), 1e-30f);
     x_inv = 448.f * __builtin_amdgcn_rcpf(amax);
     if ((olane() & 31) == i) sx_n = amax * (1.f / 448.f);
   };
   auto x_quant2b = [&](int i) {                          // convert (saturating: MODE.FP16_OVFL) and store into the image
     const int l = olane();
+    if constexpr (XQ) {                                  // the arrived row is e4m3 already: raw row -> image (lanes l and l + 32 write the same bytes)
+      *reinterpret_cast<u32x4*>(img + i * kImgRow + 16 * (l & 31)) = *reinterpret_cast<const u32x4*>(rawb + (i & 1) * 2048 + 16 * (l & 31));
+      return;
+    }
     const char* src = rawb + (i & 1) * 2048 + l * 16;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 1024);
@@ -547,6 +608,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const unsigned char* w1n = w1 + (size_t)nxt.e * F * kD;
     const unsigned char* w2n = w2 + (size_t)nxt.e * F * kD;
     if (has_next) my_src_n = pos[min(tile_row0_n + r, row_end_n - 1)];
+    if constexpr (XQ) { if (has_next) sx_n = xq_scale[my_src_n]; }
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -556,6 +618,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     // settle the pos load HERE (behind the zeroing): a load still pending in hipcc's model at the loop head would put an
     // s_waitcnt vmcnt(0) in front of every fill of the loop, draining the weight loads in flight each time
     asm volatile("" : "+v"(my_src_n));
+    if constexpr (XQ) asm volatile("" : "+v"(sx_n));
 
     M3_DIAG(const unsigned long long t_begin = __builtin_amdgcn_s_memtime();)
     // step t: barrier (every wave is done reading slot (t + 1) & 1, piece t is visible) -> MFMAs on piece t, and between the
@@ -605,9 +668,15 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
             }
           } else if (q == 0 && s >= 16) {
             const int p = (s - 16) >> 1;
+            // (the z blocks come from asm MFMAs: hipcc does not know they are matrix-pipe results and is free to place these
+            //  VALU reads right behind slot 15's last MFMA -- inside a slot nothing orders them against the slot's own MFMAs.
+            //  Without the settle the XQ instantiation's schedule read accumulator registers before they were written back:
+            //  0.1 of |y| 2.6 wrong, deterministic; the builtin-MFMA build (-DM3_F8_ASM_MFMA=0) was bit-identical to the other form)
+            if (s == 16) mfma8_v_settle(acc_a);
             silu_pair(acc_a, 0, p, sl_rel, p < 7 ? 0 : 1, p < 7 ? p + 1 : 0);
           } else if (q == 1 && s < 16) {
             const int p = s >> 1;
+            if (s == 0) mfma8_v_settle(acc_b);
             silu_pair(acc_b, 1, p, p < 7 ? sl_rel : sl_rel_next, p < 7 ? 1 : 0, p < 7 ? p + 1 : 0);
           }
         };
@@ -753,17 +822,53 @@ int init_expert_ffn_fused_fp8_kernels() {
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_fused_fp8_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   once.mark();
   return 0;
 }
 
+#ifdef M3_XQ_SELFTEST   // debug build: the stand-alone operator quantises its rows with a kernel of its own and runs the XQ form
+__global__ __launch_bounds__(256) void rows_to_e4m3_kernel(const float* __restrict__ x, int ldx, int S, unsigned char* __restrict__ xq,
+                                                           float* __restrict__ sc) {
+  __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  const f32x4 v0 = ldg4(x + (size_t)row * ldx + 4 * lane), v1 = ldg4(x + (size_t)row * ldx + 256 + 4 * lane);
+  float amax = 0.f;
+  for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+  amax = fmaxf(wave_max(amax), 1e-30f);
+  const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
+  int q0 = 0, q1 = 0;
+  q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
+  q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
+  q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0] * inv, v1[1] * inv, q1, false);
+  q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2] * inv, v1[3] * inv, q1, true);
+  *reinterpret_cast<int*>(xq + (size_t)row * 512 + 4 * lane) = q0;
+  *reinterpret_cast<int*>(xq + (size_t)row * 512 + 256 + 4 * lane) = q1;
+  if (lane == 0) sc[row] = amax * (1.f / 448.f);
+}
+#endif
+
 int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                                float h_scale, float* ybuf, hipStream_t stream) {
+                                float h_scale, float* ybuf, hipStream_t stream, const void* xq, const float* xq_scale) {
+  M3_REQUIRE(xq == nullptr || xq_scale != nullptr, "expert_ffn_fused_fp8: quantised rows without their scales");
   M3_REQUIRE(expert_ffn_fused_fp8_applies(S, E, D, F), "expert_ffn_fused_fp8: shape S=%d E=%d D=%d F=%d not supported", S, E, D, F);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_fused_fp8: ldx=%d must be a multiple of 4", ldx);
   M3_REQUIRE(h_scale > 0.f, "expert_ffn_fused_fp8: h_scale must be positive (got %g)", (double)h_scale);
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
+#ifdef M3_XQ_SELFTEST
+  if (xq == nullptr && getenv("M3_XQ_SELFTEST_ON")) {
+    static unsigned char* t_xq = nullptr; static float* t_sc = nullptr; static int t_rows = 0;
+    if (t_rows < S) { if (t_xq) { (void)hipFree(t_xq); (void)hipFree(t_sc); } M3_CHECK_HIP(hipMalloc(&t_xq, (size_t)S * 512)); M3_CHECK_HIP(hipMalloc(&t_sc, (size_t)S * 4)); t_rows = S; }
+    const int var = getenv("M3_XQ_VAR") ? atoi(getenv("M3_XQ_VAR")) : 0;
+    M3_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xq_var), &var, sizeof(int)));
+    hipLaunchKernelGGL(rows_to_e4m3_kernel, dim3((S + 3) / 4), dim3(256), 0, stream, x, ldx, S, t_xq, t_sc);
+    xq = t_xq; xq_scale = t_sc;
+  }
+#endif
   const int fsplit = expert_ffn_fused_fp8_fsplit(S, E, D, F);
   M3_REQUIRE((size_t)S * ldx * 4 < ((size_t)1 << 32), "expert_ffn_fused_fp8: input of %d rows x %d floats exceeds a 4-GB buffer", S, ldx);
   const int nblk = fused8_grid();
@@ -771,8 +876,16 @@ int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, con
   const int slice_stride = w2_sliced ? D * 64 : 64;          // bytes between consecutive 64-wide f slices
   const size_t lds = kLdsBytes;
 #define M3_FUSED8_LAUNCH(FS_)                                                                                              \
-  hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, E, \
-                     F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride, h_scale, ybuf)
+  do {                                                                                                                     \
+    if (xq != nullptr)                                                                                                     \
+      hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_, true>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, \
+                         E, F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride,  \
+                         h_scale, ybuf, (const unsigned char*)xq, xq_scale);                                              \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_, false>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, \
+                         E, F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride,  \
+                         h_scale, ybuf, (const unsigned char*)nullptr, (const float*)nullptr);                            \
+  } while (0)
   if (fsplit == 4) M3_FUSED8_LAUNCH(4); else if (fsplit == 2) M3_FUSED8_LAUNCH(2); else M3_FUSED8_LAUNCH(1);
 #undef M3_FUSED8_LAUNCH
   M3_LAUNCH_CHECK();

@@ -28,8 +28,13 @@ __global__ __launch_bounds__(256, 2) void moe_router_kernel(const float* __restr
                                                             float* __restrict__ Y, int ldy, int M, int N,
                                                             const int32_t* __restrict__ m_dev,
                                                             int32_t* __restrict__ gate_idx, float* __restrict__ gate_val,
-                                                            const int32_t* __restrict__ row_len, int rows_per_batch) {
+                                                            const int32_t* __restrict__ row_len, int rows_per_batch,
+                                                            unsigned char* __restrict__ xq, float* __restrict__ xq_scale) {
   extern __shared__ __attribute__((aligned(16))) float rt_lds[];
+  // xq != null (D == 512): the normalised rows also leave as e4m3 with a per-row scale -- exactly the quantisation the fused fp8
+  // expert kernel applies to its input rows (moe_expert_fused_fp8.hip: amax / 448, reciprocal, saturating conversion; the
+  // conversions need MODE.FP16_OVFL, which touches nothing else in this kernel), so that kernel reads 512 B per row instead of 2 KB
+  if (xq != nullptr) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 16;
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void moe_router_kernel(const float* __restr
       }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    f32x4 o2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = 4 * lane + 256 * j;
@@ -135,7 +141,29 @@ __global__ __launch_bounds__(256, 2) void moe_router_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) o[e] = (v[i][j][e] - mean) * rstd * ga[j][e] + be[j][e];
         *reinterpret_cast<f32x4*>(Xs + r * x_ld + c) = o;
         if (live && xn != nullptr) stg4(xn + (size_t)m * ldxn + c, o);
+        o2[j] = o;
       }
+    }
+    if (xq != nullptr) {                               // (D == 512: the lane's 8 values are the whole of its share of the row)
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(o2[0][e]), fabsf(o2[1][e])));
+      amax = fmaxf(wave_max(amax), 1e-30f);
+      const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
+      int q0 = 0, q1 = 0;
+      q0 = __builtin_amdgcn_cvt_pk_fp8_f32(o2[0][0] * inv, o2[0][1] * inv, q0, false);
+      q0 = __builtin_amdgcn_cvt_pk_fp8_f32(o2[0][2] * inv, o2[0][3] * inv, q0, true);
+      q1 = __builtin_amdgcn_cvt_pk_fp8_f32(o2[1][0] * inv, o2[1][1] * inv, q1, false);
+      q1 = __builtin_amdgcn_cvt_pk_fp8_f32(o2[1][2] * inv, o2[1][3] * inv, q1, true);
+      if (live) {
+        *reinterpret_cast<int*>(xq + (size_t)m * 512 + 4 * lane) = q0;
+        *reinterpret_cast<int*>(xq + (size_t)m * 512 + 256 + 4 * lane) = q1;
+        if (lane == 0) xq_scale[m] = amax * (1.f / 448.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = 4 * lane + 256 * j;
       if (c < De) *reinterpret_cast<f32x4*>(Es + r * e_ld + c) = ev[i][j];
       if (wide) {
         const int c2 = 512 + c;
@@ -251,7 +279,8 @@ int init_moe_router_kernels() {
 int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx, int D, const float* W, const float* bias,
                       const float* gamma, const float* beta, float eps, float* xn, int ldxn, float* Y, int ldy, int M, int N,
                       const int32_t* m_dev, hipStream_t stream, int32_t* gate_idx, float* gate_val, const int32_t* row_len,
-                      int rows_per_batch) {
+                      int rows_per_batch, void* xq, float* xq_scale) {
+  M3_REQUIRE(xq == nullptr || (D == 512 && xq_scale != nullptr), "moe_router: quantised rows need D == 512 and a scale buffer");
   M3_REQUIRE(M > 0 && moe_router_supports(De, D, N), "moe_router: unsupported problem M=%d De=%d D=%d N=%d", M, De, D, N);
   M3_REQUIRE((lde & 3) == 0 && (ldx & 3) == 0 && (xn == nullptr || (ldxn & 3) == 0), "moe_router: row strides must be multiples of 4");
   M3_REQUIRE(emb && x && W && gamma && beta && Y, "moe_router: null pointer");
@@ -277,7 +306,7 @@ int launch_moe_router(const float* emb, int lde, int De, const float* x, int ldx
   dim3 grid(rows16, cdiv(tiles, nt));
 #define M3_ROUTER_CASE(NT_)                                                                                              \
   hipLaunchKernelGGL((moe_router_kernel<NT_>), grid, dim3(256), lds, stream, emb, lde, De, x, ldx, D, W, bias, gamma, beta, \
-                     eps, xn, ldxn, Y, ldy, M, N, m_dev, gate_idx, gate_val, row_len, rows_per_batch)
+                     eps, xn, ldxn, Y, ldy, M, N, m_dev, gate_idx, gate_val, row_len, rows_per_batch, (unsigned char*)xq, xq_scale)
   if (nt == 1) M3_ROUTER_CASE(1); else if (nt == 2) M3_ROUTER_CASE(2); else M3_ROUTER_CASE(4);
 #undef M3_ROUTER_CASE
   M3_LAUNCH_CHECK();
