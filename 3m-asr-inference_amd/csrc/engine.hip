@@ -278,6 +278,7 @@ struct Plan {
   int32_t* lens;
   float *c1, *c2, *x, *emb, *h1, *qkv, *pbuf, *ctx, *glu, *dw, *xn, *rl, *eall;
   void* xb;                             // bf16 copy of the residual stream (16-bit modes, long batches)
+  int32_t* moe_fs;                      // fp8 plans: the F split the fused expert kernel chose on the device (slab count for the combine)
   unsigned char* xq; float* xq_scale;   // fp8 plans: the MoE input rows as e4m3 [S][D] + per-row scales (router kernel -> fused fp8 expert kernel)
   float* xstats;                        // [S][kXbStatParts][2]: row statistics of xb for the folded-LayerNorm GEMMs (gemm_bf16_dma.hip)
   int32_t* gate_idx; float* gate_val;   // [n_moe][S]
@@ -331,7 +332,8 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
   p.glu = cv.take<float>((size_t)S * D);
   p.dw = cv.take<float>((size_t)S * D);
   p.xn = cv.take<float>((size_t)S * D);
-  p.xq = nullptr; p.xq_scale = nullptr;
+  p.xq = nullptr; p.xq_scale = nullptr; p.moe_fs = nullptr;
+  if (c.weight_dtype == M3_FP8) p.moe_fs = cv.take<int32_t>(64);
   if (c.weight_dtype == M3_FP8 && D == 512) {
     p.xq = cv.take<unsigned char>((size_t)S * D);
     p.xq_scale = cv.take<float>((size_t)S);
@@ -676,6 +678,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const bool split_route = c.fuse_route == 2 && world == 1 && S < 1024 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
     bool router_gate = false;   // the dedicated router kernel also did SoftmaxTopK (no moe_top1 stage)
     bool use_xq = false;        // ... and left the rows quantised for the fused fp8 expert kernel
+    int32_t* fs_dev = nullptr;  // the fused fp8 kernel's device-side F split (slab count), when it is allowed to choose
     if (split_route) {
       GemmParams r;
       r.A = x; r.lda = D; r.W = w.router_x.w; r.bias = w.router_x.b; r.ln_wsum = w.router_x.wsum; r.ln_eps = eps;
@@ -826,11 +829,18 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const bool e16 = c.weight_dtype != M3_F32, e8 = c.weight_dtype == M3_FP8;
     const float *es1 = w.es1, *es2 = w.es2;
     const float h_scale = w.h_scale;
+    // all experts local, fused fp8 kernel, M3_FUSED8_ADAPT=1: the kernel may split F finer than the host's choice when the routing
+    // leaves CUs without an item (the expert-parallel receive side always keeps the host's split: its result stays comparable bit
+    // for bit with any other grouping of the same rows under the same split).  A latency / throughput trade, OFF by default:
+    // measured at configs[4]'s share on one box, the launch 38.5 -> 27.8 us and one forward alone 6.70 -> 6.57 ms, but 4.58 -> 4.45 M
+    // frames/s at four contexts (twice the partial-output slabs; the idle CUs were being used by the other contexts' kernels)
+    static const int adapt_on = [] { const char* ev = getenv("M3_FUSED8_ADAPT"); return ev ? atoi(ev) : 0; }();
+    fs_dev = (adapt_on && e8 && h_scale > 0.f && pl.moe_fs != nullptr && !c.debug_taps && expert_ffn_w8a8_fused(S, E, D, F)) ? pl.moe_fs : nullptr;
     const int wmode = e8 ? (h_scale > 0.f ? 3 : 2) : (e16 ? 1 : 0);
     const int elaunches = e16 ? expert_ffn_w16_launches(wmode, S, E, D, F) : (expert_ffn_f32_tiled(S, E, D, F) ? 2 : 1);
     add_stage(e, pfx + "moe_local.expert", elaunches, [=](hipStream_t s) {
       if (e8) return launch_expert_ffn_w8a8(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, es1, eb1, ew2, es2, 1, h_scale, mw.slab, s,
-                                            use_xq ? pl.xq : nullptr, use_xq ? pl.xq_scale : nullptr);
+                                            use_xq ? pl.xq : nullptr, use_xq ? pl.xq_scale : nullptr, fs_dev);
       if (e16) return launch_expert_ffn_bf16w(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, s);
       return launch_expert_ffn_f32(xn, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, nullptr, nullptr, 0.f, s);
     }, stage_info(e16 ? expert_ffn_w16_kernel(wmode, S, E, D, F)
@@ -849,8 +859,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const int32_t* cmap = self_route ? nullptr : mw.mapping;
     const float* cb2 = self_route ? nullptr : eb2;
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
-      return launch_moe_combine(erows, eslices, cmap, gidx, gv, cb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
-                                dma ? xstats : nullptr);
+      return launch_moe_combine(erows, fs_dev ? 4 : eslices, cmap, gidx, gv, cb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
+                                dma ? xstats : nullptr, fs_dev);
     }, stage_info("moe_combine_kernel", 1, (double)S * D * 4 * (eslices + 2) + (a16 ? 2.0 * S * D : 0.0), (double)S * D * (eslices + 10)));
     }
     const std::string b = pfx.substr(0, pfx.size() - 1);

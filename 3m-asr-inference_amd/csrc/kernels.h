@@ -151,12 +151,14 @@ int expert_ffn_fused_fp8_fsplit(int S, int E, int D, int F);
 int init_expert_ffn_fused_fp8_kernels();
 int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                                float h_scale, float* ybuf, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr);
+                                float h_scale, float* ybuf, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr,
+                                int32_t* fs_dev = nullptr);   // fs_dev: the kernel may split F finer than the host's choice and leaves the slab count there
 // fp8 weights, dispatcher: h_scale > 0 asks for fp8 activations (taken where the fused kernel applies)
 bool expert_ffn_w8a8_fused(int S, int E, int D, int F);   // ... i.e. when this holds (moe_expert_bf16.hip)
 int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                            const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                           float h_scale, float* slab, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr);
+                           float h_scale, float* slab, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr,
+                           int32_t* fs_dev = nullptr);
 // long batches: two grouped GEMMs on the LDS-tiled bf16 core (gemm_bf16_tiled.hip); hbuf S*F bf16, ybuf S*D fp32
 // b2 / y_scatter (optional): GEMM-2 adds the expert's b2 and writes row i of the sorted order to row pos[i] of y_scatter
 // (the un-permute of the expert-parallel receive side, folded into the epilogue)
@@ -180,7 +182,8 @@ int launch_expert_ffn_bf16_g256(const void* xb, int ldxb, const int32_t* pos, co
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream, void* out_bf16 = nullptr, float* out_stats = nullptr);
+                       hipStream_t stream, void* out_bf16 = nullptr, float* out_stats = nullptr,
+                       const int32_t* n_slices_dev = nullptr);   // n_slices_dev: the slab count is a device value (<= n_slices)
 
 // ---- row-wise ops (rowops.hip) ----
 int launch_layernorm(const float* x, const float* gamma, const float* beta, float eps, float* y, int rows, int D,

@@ -413,10 +413,12 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
                                                           const float* resid, float alpha,
                                                           const float* __restrict__ ln_gamma,
                                                           const float* __restrict__ ln_beta, float ln_eps,
-                                                          float* out, int S, int D, bf16_t* out_b, float* out_stats) {
+                                                          float* out, int S, int D, bf16_t* out_b, float* out_stats,
+                                                          const int32_t* __restrict__ n_slices_dev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.x * 4 + wave;
   if (s >= S) return;
+  if (n_slices_dev != nullptr) n_slices = min(n_slices, *n_slices_dev);   // (the fused fp8 kernel chose its F split on the device)
   const int g = gate_idx ? gate_idx[s] : 0;
   const int m = mapping ? mapping[s] : (g >= 0 ? s : -1);
   const float gate = (m >= 0) ? (gate_value ? gate_value[s] : 1.f) : 0.f;
@@ -513,14 +515,14 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const float* __restric
 int launch_moe_combine(const float* slab, int n_slices, const int32_t* mapping, const int32_t* gate_idx,
                        const float* gate_value, const float* b2, const float* resid, float alpha,
                        const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int S, int D,
-                       hipStream_t stream, void* out_bf16, float* out_stats) {
+                       hipStream_t stream, void* out_bf16, float* out_stats, const int32_t* n_slices_dev) {
   M3_REQUIRE((D & 3) == 0 && D <= 2048, "moe_combine: D=%d must be a multiple of 4 (<=2048)", D);
   if (S == 0) return 0;
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(S, 4));
 #define M3_COMBINE_CASE(NV_)                                                                              \
   hipLaunchKernelGGL((moe_combine_kernel<NV_>), grid, dim3(256), 0, stream, slab, n_slices, mapping,     \
-                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D, (bf16_t*)out_bf16, out_stats)
+                     gate_idx, gate_value, b2, resid, alpha, ln_gamma, ln_beta, ln_eps, out, S, D, (bf16_t*)out_bf16, out_stats, n_slices_dev)
   if (nv <= 1) M3_COMBINE_CASE(1); else if (nv <= 2) M3_COMBINE_CASE(2); else if (nv <= 4) M3_COMBINE_CASE(4); else M3_COMBINE_CASE(8);
 #undef M3_COMBINE_CASE
   M3_LAUNCH_CHECK();

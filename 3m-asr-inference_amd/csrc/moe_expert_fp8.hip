@@ -212,10 +212,10 @@ int launch_expert_ffn_w8(const float* x, int ldx, const int32_t* pos, const int3
 bool expert_ffn_w8a8_fused(int S, int E, int D, int F);   // moe_expert_bf16.hip (layout helpers)
 int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                            const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                           float h_scale, float* slab, hipStream_t stream, const void* xq, const float* xq_scale) {
+                           float h_scale, float* slab, hipStream_t stream, const void* xq, const float* xq_scale, int32_t* fs_dev) {
   // (xq / xq_scale: the rows already quantised by the router kernel -- only the fused kernel takes them; x stays valid for the other form)
   if (h_scale > 0.f && expert_ffn_w8a8_fused(S, E, D, F))
-    return launch_expert_ffn_fused_fp8(x, ldx, pos, acc_hist, S, E, D, F, w1, s1, b1, w2, s2, w2_sliced, h_scale, slab, stream, xq, xq_scale);
+    return launch_expert_ffn_fused_fp8(x, ldx, pos, acc_hist, S, E, D, F, w1, s1, b1, w2, s2, w2_sliced, h_scale, slab, stream, xq, xq_scale, fs_dev);
   return launch_expert_ffn_w8(x, ldx, pos, acc_hist, S, E, D, F, w1, s1, b1, w2, s2, w2_sliced, slab, stream);
 }
 

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const float* __restrict__ x, int ldx, const int32_t* __restrict__ pos, const int32_t* __restrict__ acc_hist, int S, int E,
     int F, const unsigned char* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ b1,
     const unsigned char* __restrict__ w2, const float* __restrict__ s2, int w2_row_stride, int w2_slice_stride, float h_scale,
-    float* __restrict__ ybuf, const unsigned char* __restrict__ xq_in, const float* __restrict__ xq_scale) {
+    float* __restrict__ ybuf, const unsigned char* __restrict__ xq_in, const float* __restrict__ xq_scale,
+    int32_t* __restrict__ fs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -244,7 +245,20 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     for (int d = 32; d >= 1; d >>= 1) nt += __shfl_xor(nt, d, 64);
     total_tiles += nt;
   }
-  const int items = __builtin_amdgcn_readfirstlane(total_tiles) * FSPLIT;
+  // F parts per token tile.  FSPLIT is the host's choice from the PADDED row count; fs_out != null (all experts local): the
+  // tile count is known here, and when it leaves CUs without an item the split is made finer (every work-group derives the same
+  // value; it is left in *fs_out for the combine, which sums that many slabs): configs[4]'s share has ~50-64 tiles -- 100-128
+  // items of 832 KB at FSPLIT = 2 on 256 CUs, 200-256 items of 576 KB at 4
+  int fsplit = FSPLIT;
+  {
+    const int tt_ = __builtin_amdgcn_readfirstlane(total_tiles);
+    if (fs_out != nullptr) {
+      if (tt_ * 4 <= (int)gridDim.x && F % 512 == 0) fsplit = 4;
+      else if (tt_ * 2 <= (int)gridDim.x && F % 256 == 0 && FSPLIT < 2) fsplit = 2;
+      if (blockIdx.x == 0 && threadIdx.x == 0) *fs_out = fsplit;
+    }
+  }
+  const int items = __builtin_amdgcn_readfirstlane(total_tiles) * fsplit;
   const int per = (items + 7) >> 3;
   const int stride = gridDim.x >> 3;
   const int item_end = min(((int)(blockIdx.x & 7) + 1) * per, items);
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   if (item >= item_end) return;                        // (uniform over the work-group)
   M3_DIAG(const unsigned long long t_k0 = __builtin_amdgcn_s_memtime();)
 
-  const int nsl = F / (64 * FSPLIT);                   // 64-wide slices of F a work item contracts
+  const int nsl = F / (64 * fsplit);                   // 64-wide slices of F a work item contracts
   const int np = 2 * nsl;                              // pieces (= steps) per work item
   float* b1_lds = reinterpret_cast<float*>(smem + kOffBias);
   float* s1_lds = b1_lds + 1024;
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
   char* rawb = smem + kOffRaw + wv * 4096;
 
   // ---- the current work item (everything below is wave-uniform and lives in SGPRs) ----
-  TileRef cur = find_tile(acc_hist, E, item, FSPLIT, lane);
+  TileRef cur = find_tile(acc_hist, E, item, fsplit, lane);
   if (cur.e < 0) return;
   int row_end = acc_hist[cur.e + 1];
   int tile_row0 = acc_hist[cur.e] + cur.tt * kTok + wv * 32;
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     const int item_n = item + stride;
     const bool has_next = item_n < item_end;
     TileRef nxt = cur;
-    if (has_next) nxt = find_tile(acc_hist, E, item_n, FSPLIT, lane);
+    if (has_next) nxt = find_tile(acc_hist, E, item_n, fsplit, lane);
     const int row_end_n = acc_hist[nxt.e + 1];
     const int tile_row0_n = acc_hist[nxt.e] + nxt.tt * kTok + wv * 32;
     const int sl0_n = nxt.fs * nsl, phase0_n = (nxt.tt * 5) % nsl;
@@ -853,7 +867,7 @@ __global__ __launch_bounds__(256) void rows_to_e4m3_kernel(const float* __restri
 
 int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
-                                float h_scale, float* ybuf, hipStream_t stream, const void* xq, const float* xq_scale) {
+                                float h_scale, float* ybuf, hipStream_t stream, const void* xq, const float* xq_scale, int32_t* fs_dev) {
   M3_REQUIRE(xq == nullptr || xq_scale != nullptr, "expert_ffn_fused_fp8: quantised rows without their scales");
   M3_REQUIRE(expert_ffn_fused_fp8_applies(S, E, D, F), "expert_ffn_fused_fp8: shape S=%d E=%d D=%d F=%d not supported", S, E, D, F);
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_fused_fp8: ldx=%d must be a multiple of 4", ldx);
@@ -880,11 +894,11 @@ int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, con
     if (xq != nullptr)                                                                                                     \
       hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_, true>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, \
                          E, F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride,  \
-                         h_scale, ybuf, (const unsigned char*)xq, xq_scale);                                              \
+                         h_scale, ybuf, (const unsigned char*)xq, xq_scale, fs_dev);                                      \
     else                                                                                                                   \
       hipLaunchKernelGGL((expert_ffn_fused_fp8_kernel<FS_, false>), dim3(nblk), dim3(256), lds, stream, x, ldx, pos, acc_hist, S, \
                          E, F, (const unsigned char*)w1, s1, b1, (const unsigned char*)w2, s2, row_stride, slice_stride,  \
-                         h_scale, ybuf, (const unsigned char*)nullptr, (const float*)nullptr);                            \
+                         h_scale, ybuf, (const unsigned char*)nullptr, (const float*)nullptr, fs_dev);                    \
   } while (0)
   if (fsplit == 4) M3_FUSED8_LAUNCH(4); else if (fsplit == 2) M3_FUSED8_LAUNCH(2); else M3_FUSED8_LAUNCH(1);
 #undef M3_FUSED8_LAUNCH
