@@ -719,13 +719,15 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     if (moe_router_supports(De, D, Etot) && S >= router_min_rows) {
       // the dedicated kernel: one work-group per 16 rows and all experts, every activation byte read once (moe_router.hip)
       const float* emb = pl.emb; const float* rw = w.router.w; const float* rb = w.router.b;
-      // fp8 arithmetic, all experts local, the fused expert kernel next: the rows leave the router kernel quantised (e4m3 + a scale
-      // per row) and the fp32 copy is not written at all (nothing else reads xn; debug taps keep it).  M3_ROUTER_XQ=0: as before
+      // fp8 arithmetic, all experts local, the fused expert kernel next: the rows ALSO leave the router kernel quantised (e4m3 + a
+      // scale per row): the expert kernel reads 512 B per row instead of 2 KB.  M3_ROUTER_XQ=0: as before
       static const int xq_on = [] { const char* ev = getenv("M3_ROUTER_XQ"); return ev ? atoi(ev) : 1; }();
       use_xq = xq_on && pl.xq != nullptr && world == 1 && c.ep_stages <= 0 && c.weight_dtype == M3_FP8 && w.h_scale > 0.f &&
                expert_ffn_w8a8_fused(S, E, D, F);     // (the form launch_expert_ffn_w8a8 will take)
       unsigned char* xq = use_xq ? pl.xq : nullptr; float* xqs = use_xq ? pl.xq_scale : nullptr;
-      float* xn_out = (use_xq && !c.debug_taps) ? nullptr : xn;
+      // (the fp32 rows stay available as the "xn" buffer -- the calibration tools read them -- unless M3_ROUTER_SKIP_XN=1)
+      static const int skip_xn = [] { const char* ev = getenv("M3_ROUTER_SKIP_XN"); return ev ? atoi(ev) : 0; }();
+      float* xn_out = (use_xq && skip_xn && !c.debug_taps) ? nullptr : xn;
       add_stage(e, pfx + "moe_router", 1, [=](hipStream_t s) {
         // (+ SoftmaxTopK in its tail when the row-parallel top-1 launch would follow: gate_idx / gate_value come from here)
         return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn_out, D, rl, Etot, S, Etot, pdev, s,
