@@ -94,6 +94,7 @@ struct m3_engine {
     bool a16 = false;   // activations that only feed GEMMs are kept as bf16 (h1, ctx, dw, c1, c2) + a bf16 copy of x
     bool dma = false;   // a16 and the block GEMMs run on the LDS-DMA kernel: every kernel that writes xb also leaves its row statistics
     bool packed = false;   // ragged batch: the blocks run on the packed valid rows (cfg.packed_rows)
+    bool xn_skipped = false;   // the router kernel was told not to write the fp32 MoE input rows (M3_ROUTER_SKIP_XN=1)
     // (build-time scratch of the stage list) the next conv1 stage also forms the subsampled lengths; a second LayerNorm
     // for the next norm_final stage
     bool lens_in_conv1 = false;
@@ -728,6 +729,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       // (the fp32 rows stay available as the "xn" buffer -- the calibration tools read them -- unless M3_ROUTER_SKIP_XN=1)
       static const int skip_xn = [] { const char* ev = getenv("M3_ROUTER_SKIP_XN"); return ev ? atoi(ev) : 0; }();
       float* xn_out = (use_xq && skip_xn && !c.debug_taps) ? nullptr : xn;
+      if (xn_out == nullptr) e->cur.xn_skipped = true;   // ("xn" is then not offered as a buffer: a reader fails instead of reading stale rows)
       add_stage(e, pfx + "moe_router", 1, [=](hipStream_t s) {
         // (+ SoftmaxTopK in its tail when the row-parallel top-1 launch would follow: gate_idx / gate_value come from here)
         return launch_moe_router(emb, De, De, x, D, D, rw, rb, ng, nb, eps, xn_out, D, rl, Etot, S, Etot, pdev, s,
@@ -1036,7 +1038,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   e->cur.ep_cap = e->ep_capacity;
   e->cur.sstate = sstate; e->cur.s_hist = s_hist; e->cur.s_maxf = s_maxf;
   const bool streaming = sstate != nullptr;
-  e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false;
+  e->cur.stages.clear(); e->cur.buffers.clear(); e->cur.n_kernels = 0; e->cur.graph_valid = false; e->cur.xn_skipped = false;
   e->cur.splitk_ws = pl.splitk; e->cur.splitk_bytes = pl.splitk_bytes;
   {
     // bf16 activation operands need every GEMM that reads or rewrites them on the LDS-tiled kernel: the narrowest ones
@@ -1188,7 +1190,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
               stage_info("advance_counter_kernel", 1, 8.0, 0.0, false));
   }
   e->cur.buffers["x"] = Buf{pl.x, (size_t)S * D * 4};
-  e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
+  if (!e->cur.xn_skipped) e->cur.buffers["xn"] = Buf{pl.xn, (size_t)S * D * 4};
   if (pl.xq != nullptr) {
     e->cur.buffers["xq"] = Buf{pl.xq, (size_t)S * D};
     e->cur.buffers["xq_scale"] = Buf{pl.xq_scale, (size_t)S * 4};
