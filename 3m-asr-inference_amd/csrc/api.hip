@@ -43,7 +43,8 @@ int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, 
                       const float* b2, int S, int E, int D, int F, const float* gate_value, const float* resid,
                       float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y, void* ws,
                       size_t ws_bytes, hipStream_t stream, int wmode /* 0 fp32, 1 bf16, 2 fp8 weights, 3 fp8 weights + activations */,
-                      const float* s1 = nullptr, const float* s2 = nullptr, float h_scale = 0.f) {
+                      const float* s1 = nullptr, const float* s2 = nullptr, float h_scale = 0.f, const void* xq = nullptr,
+                      const float* xq_scale = nullptr) {
   M3_REQUIRE(S >= 0 && E > 0 && D > 0 && F > 0, "fmoe_expert: bad sizes S=%d E=%d D=%d F=%d", S, E, D, F);
   if (S == 0) return 0;
   MoeWorkspace w = carve_moe_workspace(ws, S, E, D, F);
@@ -51,7 +52,7 @@ int moe_expert_ffn_dt(const float* x, const int32_t* gate_idx, const float* w1, 
              w.bytes);
   int rc = launch_moe_index(gate_idx, S, E, w.mapping, w.acc, w.pos, stream);
   if (rc) return rc;
-  if (wmode == 3) rc = launch_expert_ffn_w8a8(x, D, w.pos, w.acc, S, E, D, F, w1, s1, b1, w2, s2, 0, h_scale, w.slab, stream);
+  if (wmode == 3) rc = launch_expert_ffn_w8a8(x, D, w.pos, w.acc, S, E, D, F, w1, s1, b1, w2, s2, 0, h_scale, w.slab, stream, xq, xq_scale);
   else if (wmode == 2) rc = launch_expert_ffn_w8(x, D, w.pos, w.acc, S, E, D, F, w1, s1, b1, w2, s2, 0, w.slab, stream);
   else if (wmode) rc = launch_expert_ffn_bf16w(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, stream);
   else rc = launch_expert_ffn_f32(x, D, w.pos, w.acc, S, E, D, F, w1, b1, w2, 0, w.slab, nullptr, nullptr, 0.f, stream);
@@ -130,6 +131,23 @@ int m3_moe_expert_ffn_fp8a8(const float* x, const int32_t* gate_idx, const void*
   return moe_expert_ffn_dt(x, gate_idx, (const float*)w1, b1, (const float*)w2, b2, S, num_expert, idim, hidden_units,
                            gate_value, resid, alpha, ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes,
                            (hipStream_t)stream, 3, w1_scale, w2_scale, h_scale);
+}
+int m3_moe_expert_ffn_fp8a8_xq(const float* x, const void* xq, const float* xq_scale, const int32_t* gate_idx, const void* w1,
+                               const float* w1_scale, const float* b1, const void* w2, const float* w2_scale, const float* b2,
+                               float h_scale, int S, int num_expert, int idim, int hidden_units, const float* gate_value,
+                               const float* resid, float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               float* y, void* workspace, size_t workspace_bytes, m3_stream stream) {
+  M3_REQUIRE(w1_scale && w2_scale, "fmoe_expert fp8a8_xq: null scale");
+  M3_REQUIRE(h_scale > 0.f, "fmoe_expert fp8a8_xq: h_scale must be positive");
+  M3_REQUIRE(xq && xq_scale, "fmoe_expert fp8a8_xq: null quantised rows / scales");
+  M3_REQUIRE(expert_ffn_fused_fp8_applies(S, num_expert, idim, hidden_units) || x != nullptr,
+             "fmoe_expert fp8a8_xq: this shape takes the weight-only form, which needs the fp32 rows (x)");
+  return moe_expert_ffn_dt(x, gate_idx, (const float*)w1, b1, (const float*)w2, b2, S, num_expert, idim, hidden_units,
+                           gate_value, resid, alpha, ln_gamma, ln_beta, ln_eps, y, workspace, workspace_bytes,
+                           (hipStream_t)stream, 3, w1_scale, w2_scale, h_scale, xq, xq_scale);
+}
+int m3_quantize_rows_e4m3(const float* x, int ldx, int S, int idim, void* xq, float* scale, m3_stream stream) {
+  return launch_quantize_rows_e4m3(x, ldx, S, idim, xq, scale, (hipStream_t)stream);
 }
 int m3_moe_expert_ffn_fp8a8_active(int S, int num_expert, int idim, int hidden_units) {
   return expert_ffn_fused_fp8_applies(S, num_expert, idim, hidden_units) ? 1 : 0;

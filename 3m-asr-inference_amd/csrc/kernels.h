@@ -153,6 +153,7 @@ int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, con
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
                                 float h_scale, float* ybuf, hipStream_t stream, const void* xq = nullptr, const float* xq_scale = nullptr,
                                 int32_t* fs_dev = nullptr);   // fs_dev: the kernel may split F finer than the host's choice and leaves the slab count there
+int launch_quantize_rows_e4m3(const float* x, int ldx, int S, int D, void* xq, float* scale, hipStream_t stream);   // moe_expert_fused_fp8.hip
 // fp8 weights, dispatcher: h_scale > 0 asks for fp8 activations (taken where the fused kernel applies)
 bool expert_ffn_w8a8_fused(int S, int E, int D, int F);   // ... i.e. when this holds (moe_expert_bf16.hip)
 int launch_expert_ffn_w8a8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,

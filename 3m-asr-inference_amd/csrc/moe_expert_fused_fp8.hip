@@ -44,9 +44,6 @@ __device__ unsigned long long g_fused8_dbg[4096 * 8];
 #define M3_DIAG(...)
 #endif
 
-#ifdef M3_XQ_SELFTEST
-__device__ int g_xq_var;
-#endif
 
 namespace {
 
@@ -330,33 +327,6 @@ __global__ __launch_bounds__(256) void expert_ffn_fused_fp8_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x4*>(img + (2 * i + h) * kImgRow + 16 * r) = t[i];
-#ifdef M3_XQ_SELFTEST   // debug: g_xq_var bit 0: image from the fp32 rows (old code), bit 1: sx from the fp32 rows
-    {
-      const int var = g_xq_var;
-      if (var) {
-        float sx_old = 1.f;
-        for (int i = 0; i < 32; ++i) {
-          const float* xr = x + (size_t)__shfl(my_src, i, 64) * ldx + 4 * lane;
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 256);
-          float amax = 0.f;
-          for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
-          amax = fmaxf(wave_max(amax), 1e-30f);
-          const float inv = 448.f * __builtin_amdgcn_rcpf(amax);
-          if (r == i) sx_old = amax * (1.f / 448.f);
-          int q0 = 0, q1 = 0;
-          q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0] * inv, v0[1] * inv, q0, false);
-          q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2] * inv, v0[3] * inv, q0, true);
-          q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0] * inv, v1[1] * inv, q1, false);
-          q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2] * inv, v1[3] * inv, q1, true);
-          if (var & 1) {
-            *reinterpret_cast<int*>(img + i * kImgRow + 4 * lane) = q0;
-            *reinterpret_cast<int*>(img + i * kImgRow + 256 + 4 * lane) = q1;
-          }
-        }
-        if (var & 2) sx = sx_old;
-      }
-    }
-#endif
     read_xq();
   } else {
     const int my_src = pos[min(tile_row0 + r, row_end - 1)];          // source row of token r (lanes r and r + 32 agree)
@@ -843,7 +813,8 @@ int init_expert_ffn_fused_fp8_kernels() {
   return 0;
 }
 
-#ifdef M3_XQ_SELFTEST   // debug build: the stand-alone operator quantises its rows with a kernel of its own and runs the XQ form
+// rows -> e4m3 + one fp32 scale per row: the quantisation quant_row applies inside the fused kernel and moe_router_kernel applies to
+// the rows it normalises, as an operator of its own (m3_quantize_rows_e4m3; D = 512: one wave per row)
 __global__ __launch_bounds__(256) void rows_to_e4m3_kernel(const float* __restrict__ x, int ldx, int S, unsigned char* __restrict__ xq,
                                                            float* __restrict__ sc) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
@@ -863,7 +834,14 @@ __global__ __launch_bounds__(256) void rows_to_e4m3_kernel(const float* __restri
   *reinterpret_cast<int*>(xq + (size_t)row * 512 + 256 + 4 * lane) = q1;
   if (lane == 0) sc[row] = amax * (1.f / 448.f);
 }
-#endif
+int launch_quantize_rows_e4m3(const float* x, int ldx, int S, int D, void* xq, float* scale, hipStream_t stream) {
+  M3_REQUIRE(D == kD && (ldx & 3) == 0 && S >= 0, "quantize_rows_e4m3: D=%d must be %d, ldx=%d a multiple of 4", D, kD, ldx);
+  M3_REQUIRE(x && xq && scale, "quantize_rows_e4m3: null pointer");
+  if (S == 0) return 0;
+  hipLaunchKernelGGL(rows_to_e4m3_kernel, dim3((S + 3) / 4), dim3(256), 0, stream, x, ldx, S, (unsigned char*)xq, scale);
+  M3_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, const int32_t* acc_hist, int S, int E, int D, int F,
                                 const void* w1, const float* s1, const float* b1, const void* w2, const float* s2, int w2_sliced,
@@ -873,16 +851,6 @@ int launch_expert_ffn_fused_fp8(const float* x, int ldx, const int32_t* pos, con
   M3_REQUIRE((ldx & 3) == 0, "expert_ffn_fused_fp8: ldx=%d must be a multiple of 4", ldx);
   M3_REQUIRE(h_scale > 0.f, "expert_ffn_fused_fp8: h_scale must be positive (got %g)", (double)h_scale);
   if (int rc = init_expert_ffn_fused_fp8_kernels()) return rc;
-#ifdef M3_XQ_SELFTEST
-  if (xq == nullptr && getenv("M3_XQ_SELFTEST_ON")) {
-    static unsigned char* t_xq = nullptr; static float* t_sc = nullptr; static int t_rows = 0;
-    if (t_rows < S) { if (t_xq) { (void)hipFree(t_xq); (void)hipFree(t_sc); } M3_CHECK_HIP(hipMalloc(&t_xq, (size_t)S * 512)); M3_CHECK_HIP(hipMalloc(&t_sc, (size_t)S * 4)); t_rows = S; }
-    const int var = getenv("M3_XQ_VAR") ? atoi(getenv("M3_XQ_VAR")) : 0;
-    M3_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xq_var), &var, sizeof(int)));
-    hipLaunchKernelGGL(rows_to_e4m3_kernel, dim3((S + 3) / 4), dim3(256), 0, stream, x, ldx, S, t_xq, t_sc);
-    xq = t_xq; xq_scale = t_sc;
-  }
-#endif
   const int fsplit = expert_ffn_fused_fp8_fsplit(S, E, D, F);
   M3_REQUIRE((size_t)S * ldx * 4 < ((size_t)1 << 32), "expert_ffn_fused_fp8: input of %d rows x %d floats exceeds a 4-GB buffer", S, ldx);
   const int nblk = fused8_grid();

@@ -103,6 +103,9 @@ SIGNATURES = {
     "m3_moe_expert_ffn_fp8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp,
                                      _vp, _sz, _vp]),
     "m3_moe_expert_ffn_fp8a8_active": (_i, [_i, _i, _i, _i]),
+    "m3_moe_expert_ffn_fp8a8_xq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp,
+                                        _f, _vp, _vp, _sz, _vp]),
+    "m3_quantize_rows_e4m3": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "m3_moe_combine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "m3_moe_combine_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
     "m3_softmax_top1": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),

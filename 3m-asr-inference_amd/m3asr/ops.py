@@ -91,12 +91,25 @@ def moe_expert_workspace_size(S, E, D, F):
     return _lib.load().m3_moe_expert_workspace_size(S, E, D, F)
 
 
+def quantize_rows_e4m3(x):
+    """x (S, 512) f32 -> (xq (S, 512) uint8 holding OCP e4m3, scale (S,) f32): scale = amax / 448 per row, round to nearest even,
+    saturating -- what the fused fp8 expert kernel does to its input rows (m3_quantize_rows_e4m3)."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    S, D = x.shape
+    xq = torch.empty(S, D, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(S, dtype=torch.float32, device=x.device)
+    check(lib.m3_quantize_rows_e4m3(_p(x), x.stride(0), S, D, _p(xq), _p(scale), _stream()), "m3_quantize_rows_e4m3")
+    return xq, scale
+
+
 def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alpha=1.0, ln=None, workspace=None,
-                   w1_scale=None, w2_scale=None, out=None, h_scale=None):
+                   w1_scale=None, w2_scale=None, out=None, h_scale=None, xq=None, xq_scale=None):
     """FMoEExpert: x (S,D) f32, gate_idx (S,) i32 -> y (S,D).  Optional fused epilogue (gate, residual, LayerNorm).
     The expert weights pick the kernel family: fp32; bf16 (bf16 MFMA, fp32 accumulate); e4m3 with per-row scales
     w1_scale [E,F] / w2_scale [E,D] (dequantised to bf16 at the MFMA input; with h_scale: fp8 arithmetic, activations
-    quantised too -- m3_moe_expert_ffn_fp8a8).  Biases are fp32 in every mode."""
+    quantised too -- m3_moe_expert_ffn_fp8a8; xq / xq_scale: the rows already quantised by quantize_rows_e4m3, read instead
+    of x where the fused kernel applies -- m3_moe_expert_ffn_fp8a8_xq).  Biases are fp32 in every mode."""
     lib = _lib.load()
     assert w1.dtype == w2.dtype and w1.is_contiguous() and w2.is_contiguous()
     S, D = x.shape
@@ -112,6 +125,11 @@ def moe_expert_ffn(x, gate_idx, w1, b1, w2, b2, gate_value=None, resid=None, alp
     if w1.dtype == torch.float8_e4m3fn and h_scale is not None:
         # fp8 arithmetic: activations quantised too (rows: per-row dynamic scale; H: the static scale h_scale)
         assert w1_scale is not None and w2_scale is not None, "fp8 expert weights need their per-row scales"
+        if xq is not None:
+            assert xq.dtype in (torch.uint8, torch.float8_e4m3fn) and xq.is_contiguous() and xq.shape == x.shape and xq_scale is not None
+            check(lib.m3_moe_expert_ffn_fp8a8_xq(xi, _p(xq), _f32(xq_scale), gi, _p(w1), _f32(w1_scale), _f32(b1), _p(w2),
+                                                 _f32(w2_scale), _f32(b2), float(h_scale), *tail), "m3_moe_expert_ffn_fp8a8_xq")
+            return y
         check(lib.m3_moe_expert_ffn_fp8a8(xi, gi, _p(w1), _f32(w1_scale), _f32(b1), _p(w2), _f32(w2_scale), _f32(b2),
                                           float(h_scale), *tail), "m3_moe_expert_ffn_fp8a8")
     elif w1.dtype == torch.float8_e4m3fn:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define M3ASR_ABI_VERSION 8
+#define M3ASR_ABI_VERSION 9
 
 typedef void* m3_stream; /* hipStream_t */
 
@@ -145,6 +145,20 @@ int m3_moe_expert_ffn_fp8a8(const float* x, const int32_t* gate_idx, const void*
                             float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps, float* y,
                             void* workspace, size_t workspace_bytes, m3_stream stream);
 int m3_moe_expert_ffn_fp8a8_active(int S, int num_expert, int idim, int hidden_units);
+/* ABI 9.  The same operator on rows that are ALREADY quantised the way it quantises them itself: xq [S][idim] e4m3, xq_scale [S]
+ * (x = xq * xq_scale per row; what m3_quantize_rows_e4m3 and, inside the engine, the router kernel write).  Where the fused
+ * kernel applies (m3_moe_expert_ffn_fp8a8_active) x is not read and may be NULL, and the result is bit-identical to
+ * m3_moe_expert_ffn_fp8a8 on the fp32 rows; elsewhere the weight-only form runs on x.  Replaces nothing in the reference (its
+ * --int8 path asserts, builder.py:39-49); it is the hand-over the whole-encoder engine uses between its router kernel and its
+ * expert kernel, exposed so that it can be tested at the boundary. */
+int m3_moe_expert_ffn_fp8a8_xq(const float* x, const void* xq, const float* xq_scale, const int32_t* gate_idx, const void* w1,
+                               const float* w1_scale, const float* b1, const void* w2, const float* w2_scale, const float* b2,
+                               float h_scale, int S, int num_expert, int idim, int hidden_units, const float* gate_value,
+                               const float* resid, float alpha, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                               float* y, void* workspace, size_t workspace_bytes, m3_stream stream);
+/* rows -> OCP e4m3 with one dynamic scale per row: scale[s] = amax(x[s]) / 448 (1e-30 floor), xq = round-to-nearest-even,
+ * saturating (x[s] / scale[s]).  idim must be 512 (one wave per row). */
+int m3_quantize_rows_e4m3(const float* x, int ldx, int S, int idim, void* xq, float* scale, m3_stream stream);
 /* The tail of the MoE layer on rows that are already in scattered (expert-sorted) order, e.g. rows that came back
  * from the expert-parallel all-to-all:  out[s] = LayerNorm( resid[s] + alpha * gate_value[s] * rows[mapping[s]] )
  * (rows with mapping < 0 contribute 0; gate_value / resid / ln_* may be NULL).  = local_gather

@@ -47,7 +47,7 @@ def test_ctypes_table_matches_header(lib_path):
     from m3asr import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.m3_abi_version() == 8
+    assert lib.m3_abi_version() == 9
 
 
 def test_registry_names_are_the_references(lib_path):

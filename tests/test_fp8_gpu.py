@@ -155,6 +155,44 @@ def test_fmoe_expert_fp8_arithmetic(S, E, D, Fh, mode):
     assert q_err < 8e-2, q_err
 
 
+def test_quantize_rows_e4m3_matches_torch_conversion():
+    """m3_quantize_rows_e4m3 (= what the fused fp8 kernel and the engine's router kernel do to a row): scale = amax / 448 exactly,
+    bytes = torch's round-to-nearest-even e4m3 conversion of x * (448 / amax) -- bit for bit (rows with an exact tie between two
+    e4m3 values aside: the kernel multiplies by the hardware reciprocal of amax, torch divides)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3000, 512, generator=g) * torch.logspace(-3, 3, 3000).view(-1, 1)
+    x[17] = 0.0                                   # an all-zero row: scale floor, zeros out
+    xq, sc = ops.quantize_rows_e4m3(dev(x))
+    amax = x.abs().amax(1).clamp_min(1e-30)
+    assert torch.equal(sc.cpu(), amax * (1.0 / 448.0))
+    want = (x * (448.0 / amax).view(-1, 1)).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    neq = (xq.cpu() != want)
+    print("quantize_rows_e4m3: %d of %d bytes differ from torch's conversion" % (int(neq.sum()), neq.numel()))
+    assert int(neq.sum()) <= neq.numel() // 20000       # reciprocal vs division: a handful of exact-boundary cases at most
+    assert bool((xq.cpu()[17] == 0).all())
+
+
+@pytest.mark.parametrize("S,E", [(8192, 64), (65536, 64), (20000, 32)])
+def test_fmoe_expert_fp8_arithmetic_on_prequantised_rows_is_bit_identical(S, E):
+    """m3_moe_expert_ffn_fp8a8_xq (the hand-over between the engine's router kernel and its fused fp8 expert kernel) against
+    m3_moe_expert_ffn_fp8a8 on the fp32 rows: the same image and the same scales reach the same instructions, so every output bit
+    must agree -- one work item per work-group (8192 rows) and the persistent loop with prefetched next tiles (65536).  This is the
+    comparison that exposed the missing MFMA -> VALU wait states of the kernel's inline-asm MFMAs in round 4: the
+    two instantiations are scheduled differently, and only the hazard made them differ."""
+    D, Fh = 512, 1024
+    g, x, (w1, b1, w2, b2), (q1, s1, q2, s2) = _expert_case(S, E, D, Fh, "uniform")
+    assert ops._lib.load().m3_moe_expert_ffn_fp8a8_active(S, E, D, Fh) == 1
+    args = (dev(g), dev(q1), dev(b1), dev(q2), dev(b2))
+    kw = dict(w1_scale=dev(s1), w2_scale=dev(s2), h_scale=0.05)
+    xd = dev(x)
+    y0 = ops.moe_expert_ffn(xd, *args, **kw).clone()
+    xq, sc = ops.quantize_rows_e4m3(xd)
+    y1 = ops.moe_expert_ffn(xd, *args, xq=xq, xq_scale=sc, **kw).clone()
+    y1b = ops.moe_expert_ffn(xd, *args, xq=xq, xq_scale=sc, **kw).clone()
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(y1, y1b)
+
+
 FP8_REL = 2e-2      # weight-only e4m3 (3 mantissa bits): measured 0.9-1.0e-2 teacher-forced
 
 
