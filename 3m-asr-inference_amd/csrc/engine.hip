@@ -57,6 +57,8 @@ struct Stage {
   std::string name;
   std::function<int(hipStream_t)> run;
   m3_stage_info info;   // kernel label + algorithmic bytes / FLOPs of the stage (m3_engine_stage_info)
+  bool is_gemm = false; // a plain launch_gemm_f32 stage: `gemm` holds its problem (what horizontal fusion pairs up)
+  GemmParams gemm;
 };
 
 m3_stage_info stage_info(const char* kernel, int launches, double bytes, double flops, bool per_row = true) {
@@ -295,6 +297,7 @@ struct Plan {
   // fork_embed: the embed encoder runs on its own graph branch beside the main subsampler and block 0 up to its router
   // (conformer_fmoe_..._hier.py:206-215: embed is needed first by blocks.0's router), so it owns a second set of scratch
   bool fork;
+  bool hfuse;                           // embed chain and main prefix interleaved in one stream (separate scratch, as with fork)
   float *e_c1, *e_c2, *e_x, *e_h1, *e_qkv, *e_ctx, *e_glu, *e_dw, *e_xpad, *e_splitk, *e_xstats; void *e_xb, *e_xbpad;
   size_t bytes;
 };
@@ -303,11 +306,18 @@ struct Plan {
 // of the main encoder's start overlap the embed encoder), but four execution contexts x two branches are eight concurrently
 // active queues, past the four the part runs truly concurrently: 207 k -> 69 k frames/s.
 bool use_fork_embed(const m3_engine_config& c, int B, int S) { return c.fork_embed > 0 && !c.debug_taps; }
-
 // the blocks run on packed rows: B > 1 (or forced), no per-block taps (they are read as (B, T', D)), staged route
 bool use_packed_rows(const m3_engine_config& c, int B) {
   if (c.packed_rows < 0 || (c.packed_rows == 0 && B <= 1)) return false;
   return !c.debug_taps && c.fuse_route == 0 && B <= 1024;   // (expert-parallel ranks too: rows past the live count never travel)
+}
+
+// horizontal fusion of the embed encoder with the main encoder's independent prefix (fuse_independent_gemm_pairs): fp32 plans
+// whose block GEMMs are 16-row-tile launches (S <= 128 rows).  Needs the embed chain's scratch apart from the main chain's.
+bool use_hfuse(const m3_engine_config& c, int B, int S) {
+  static const int on = [] { const char* ev = getenv("M3_HFUSE"); return ev ? atoi(ev) : 1; }();
+  return on && !c.debug_taps && c.weight_dtype == M3_F32 && c.embed_blocks > 0 && c.num_blocks > 0 && S <= 128 && c.fork_embed <= 0 &&
+         !use_packed_rows(c, B);
 }
 
 Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capacity = 0) {
@@ -386,9 +396,10 @@ Plan make_plan(const m3_engine_config& c, void* base, int B, int T, int ep_capac
     p.lpk = cv.take<float>((size_t)S * c.output_dim);
   }
   p.fork = use_fork_embed(c, B, S);
+  p.hfuse = !p.fork && use_hfuse(c, B, S);
   p.e_c1 = p.c1; p.e_c2 = p.c2; p.e_x = p.x; p.e_h1 = p.h1; p.e_qkv = p.qkv; p.e_ctx = p.ctx; p.e_glu = p.glu; p.e_dw = p.dw;
   p.e_xb = p.xb; p.e_xpad = p.xpad; p.e_xbpad = p.xbpad; p.e_splitk = p.splitk; p.e_xstats = p.xstats;
-  if (p.fork) {
+  if (p.fork || p.hfuse) {
     p.e_c1 = cv.take<float>((size_t)B * T1 * F1 * D);
     p.e_c2 = cv.take<float>((size_t)S * F2 * D);
     p.e_x = cv.take<float>((size_t)S * D);
@@ -472,6 +483,45 @@ static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool f
     return;
   }
   add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); }, gemm_info(p, false));
+  e->cur.stages.back().is_gemm = true;
+  e->cur.stages.back().gemm = p;
+}
+
+// Horizontal fusion (B = 1-sized fp32 plans): the embed encoder and the main encoder's prefix -- its subsampling and block 0 up to
+// the router, the first stage that reads the embedding -- are two independent chains.  Where a stage of each is a skinny fp32
+// GEMM of the same instantiation, the two become ONE launch (gemm_f32_dual_kernel): a launch saved is ~6 us of a forward that is
+// 275 dependent launches.  Each chain keeps its own order; only the first embed stage (it also derives the output lengths every
+// later kernel reads) is guaranteed to stay in front of every main-prefix stage.  Arithmetic per problem is unchanged: results
+// are bit-identical.  M3_HFUSE=0: off.
+static void fuse_independent_gemm_pairs(m3_engine* e, int first, int mid, int join) {
+  if (first < 0 || mid <= first + 1 || join <= mid) return;
+  std::vector<Stage>& st = e->cur.stages;
+  std::vector<Stage> out(st.begin(), st.begin() + first);
+  std::vector<Stage> pending;                         // main-prefix stages waiting for the next pair they precede
+  int i = first, saved = 0;
+  for (int m = mid; m < join; ++m) {
+    int partner = -1;
+    if (st[m].is_gemm)
+      for (int k = std::max(i, first + 1); k < mid; ++k)
+        if (st[k].is_gemm && gemm_f32_dual_fusable(st[k].gemm, st[m].gemm)) { partner = k; break; }
+    if (partner < 0) { pending.push_back(st[m]); continue; }
+    for (; i < partner; ++i) out.push_back(st[i]);
+    for (Stage& q : pending) out.push_back(q);
+    pending.clear();
+    const GemmParams a = st[partner].gemm, b = st[m].gemm;
+    Stage d;
+    d.name = st[partner].name + "+" + st[m].name;
+    d.run = [a, b](hipStream_t s) { return launch_gemm_f32_dual(a, b, s); };
+    d.info = stage_info("gemm_f32_dual_kernel", 1, st[partner].info.alg_bytes + st[m].info.alg_bytes, st[partner].info.flops + st[m].info.flops);
+    out.push_back(d);
+    i = partner + 1;
+    ++saved;
+  }
+  for (; i < mid; ++i) out.push_back(st[i]);
+  for (Stage& q : pending) out.push_back(q);
+  for (int k = join; k < (int)st.size(); ++k) out.push_back(st[k]);
+  st.swap(out);
+  e->cur.n_kernels -= saved;
 }
 
 static void build_subsample(m3_engine* e, const std::string& pfx, const SubW& w, int D, const Plan& pl, float* xout) {
@@ -1118,6 +1168,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   }
   // ---- embed encoder (conformer_embed_domain_acc.py:149-181) ----
   const Plan ple = embed_view(pl);
+  const int hf_first = (int)e->cur.stages.size();       // (horizontal fusion: the embed chain starts here ...)
   if (pl.fork) e->cur.fork_first = (int)e->cur.stages.size();
   e->cur.splitk_ws = ple.splitk;
   build_subsample(e, "embed.subsample.", e->sub_e, De, ple, ple.x);
@@ -1146,6 +1197,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
   }
   // ---- main MoE encoder (conformer_fmoe_localComm_catEmbed_domain_acc_hier.py:198-234) ----
   if (pl.fork) e->cur.fork_mid = (int)e->cur.stages.size();
+  const int hf_mid = (int)e->cur.stages.size();         // (... and the main encoder's independent prefix here)
   build_subsample(e, "subsample.", e->sub_m, D, pl, pl.x);
   for (int i = 0; i < c.num_blocks; ++i)
     build_block(e, "blocks." + std::to_string(i) + ".", e->mblocks[i], D, c.hidden_units, c.attention_heads,
@@ -1183,6 +1235,14 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
         break;
       }
     if (e->cur.join_at < 0 || c.num_blocks < 1) e->cur.fork_first = e->cur.fork_mid = e->cur.join_at = -1;
+  }
+  if (pl.hfuse && !streaming && hf_first >= 0) {
+    int join = -1;
+    for (size_t i = (size_t)hf_mid; i < e->cur.stages.size(); ++i) {
+      const std::string& n = e->cur.stages[i].name;
+      if (n == "blocks.0.moe_router" || n == "blocks.0.moe_route" || n == "blocks.0.moe_gate_index") { join = (int)i; break; }
+    }
+    if (join > 0) fuse_independent_gemm_pairs(e, hf_first, hf_mid, join);
   }
   if (streaming) {   // the chunk counter moves on the device: the same captured graph serves every chunk of the stream
     int32_t* step = carve_stream_state(c, sstate, B, s_hist).step;

@@ -58,8 +58,12 @@ enum { LN_NONE = 0, LN_EPI = 1, LN_PRO = 2 };
 // NW = waves per workgroup = K-split factor (4 / 8 / 16 for K ~ 512 / 1024 / >= 2048).
 // NBUF = 1 when a wave's share of K fits one load group (K <= 16*NW*G: every block GEMM of the model): half the
 // staging registers -> <= 128 VGPRs -> 4 waves per SIMD, so kernels of other streams can share the CU.
+// The kernel body as a device function of (parameter block, work-group id): gemm_f32_kernel runs one problem,
+// gemm_f32_dual_kernel two INDEPENDENT problems of the same instantiation in one launch (work-groups [0, n0) the first,
+// the rest the second) -- the embed encoder and the main encoder's first block do not depend on each other until that block's
+// router, so their GEMMs can share launches (engine.hip: "horizontal fusion"; a launch saved is ~6 us of a B = 1 forward).
 template <int MT, bool GLU, int NW, bool CONV, int LN, int NBUF>
-__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmParams& p, const int bid) {
   constexpr int NT = GLU ? 2 : 1;
   constexpr int G = gemm_group_steps(MT, NT, NW);
   constexpr int RW = (16 * MT) / NW;   // rows per wave in the LN_PRO prologue (>= 1)
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   // ---- workgroup -> (column tile, row tile); XCD-aware when the column-tile count allows ----
   int n_tile, m_tile;
   {
-    const int id = blockIdx.x;
+    const int id = bid;
     if (p.xcd_swizzle) {
       const int j = id >> 3;
       m_tile = j % p.m_tiles;
@@ -422,13 +426,27 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
   M3_GDIAG(dg[6] = __builtin_amdgcn_s_memtime();
            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
            dg[7] = __builtin_amdgcn_s_memtime();
-           if (lane == 0 && wave == 0 && blockIdx.x < 2048) {
-             unsigned long long* o = g_gemm_dbg + (size_t)blockIdx.x * 8;
+           if (lane == 0 && wave == 0 && bid < 2048) {
+             unsigned long long* o = g_gemm_dbg + (size_t)bid * 8;
              for (int i = 0; i < 8; ++i) o[i] = dg[i];
              // where the work-group ran: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), packed above the last stamp's low 40 bits
              const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
              o[7] = (dg[7] & 0xffffffffffull) | ((unsigned long long)(hw & 0xffff) << 40) | ((unsigned long long)(xcc & 0xf) << 56);
            })
+}
+
+template <int MT, bool GLU, int NW, bool CONV, int LN, int NBUF>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(const GemmParams p) {
+  gemm_f32_body<MT, GLU, NW, CONV, LN, NBUF>(p, (int)blockIdx.x);
+}
+// (the second problem's work-group ids start at a multiple of 8, so that "id % 8 = XCD" holds for its XCD-aware tile order too)
+template <int MT, bool GLU, int NW, int LN>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_dual_kernel(const GemmParams p0, const GemmParams p1, const int n0) {
+  if ((int)blockIdx.x < n0) {
+    if ((int)blockIdx.x < p0.n_tiles * p0.m_tiles) gemm_f32_body<MT, GLU, NW, false, LN, 1>(p0, (int)blockIdx.x);
+  } else {
+    gemm_f32_body<MT, GLU, NW, false, LN, 1>(p1, (int)blockIdx.x - n0);
+  }
 }
 
 int launch_gemm_f32_tiled(const GemmParams& p, hipStream_t stream);   // gemm_f32_tiled.hip
@@ -454,6 +472,61 @@ const char* gemm_kernel_label(const GemmParams& p, bool splitk) {
   if (p.w_bf16 && gemm_bf16w_uses_dma(p)) return "gemm_bf16_dma_kernel";
   if (p.w_bf16) return gemm_bf16w_uses_tiled(p) ? "gemm_bf16w_tiled_kernel" : "gemm_bf16w_kernel";
   return gemm_f32_uses_tiled(p) ? "gemm_f32_tiled_kernel" : "gemm_f32_kernel";
+}
+
+// The instantiation launch_gemm_f32 runs for a problem (skinny fp32 kernel only): what two problems must share to be launched
+// together.  ok = false: not this kernel (bf16 weights, the LDS-tiled form) or not one of the dual instantiations.
+struct GemmVariant { bool ok; int mt, nw, ln; bool glu; };
+static GemmVariant gemm_f32_variant(const GemmParams& p) {
+  GemmVariant v{false, 0, 0, 0, false};
+  if (p.w_bf16 || p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 15) || p.mode != GEMM_A_PLAIN || p.ln_gamma != nullptr || p.m_dev != nullptr) return v;
+  if (gemm_f32_uses_tiled(p)) return v;
+  v.glu = p.act == ACT_GLU;
+  const int Nout = v.glu ? p.N / 2 : p.N;
+  int mt = p.M <= 128 ? 1 : (p.M <= 512 ? 2 : 4);
+  while (mt < 4 && 16 * mt < p.M && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) > 512) mt *= 2;
+  while (mt > 1 && (long)cdiv(Nout, 16) * cdiv(p.M, 16 * mt) < 256) mt /= 2;
+  v.mt = mt;
+  v.nw = p.K >= 2048 ? 16 : (p.K >= 1024 ? 8 : 4);
+  v.ln = p.ln_wsum ? LN_EPI : LN_NONE;
+  // the dual instantiations: 16-row tiles, 4 / 8 waves, one load group per wave (every block GEMM of the model at B = 1)
+  v.ok = mt == 1 && (v.nw == 4 || v.nw == 8) && (p.K >> 4) <= v.nw * gemm_group_steps(1, v.glu ? 2 : 1, v.nw);
+  return v;
+}
+bool gemm_f32_dual_fusable(const GemmParams& a, const GemmParams& b) {
+  const GemmVariant va = gemm_f32_variant(a), vb = gemm_f32_variant(b);
+  return va.ok && vb.ok && va.mt == vb.mt && va.nw == vb.nw && va.ln == vb.ln && va.glu == vb.glu;
+}
+// two independent problems of one instantiation in ONE launch (gemm_f32_dual_fusable must hold; both validated like single launches)
+int launch_gemm_f32_dual(const GemmParams& a_in, const GemmParams& b_in, hipStream_t stream) {
+  M3_REQUIRE(gemm_f32_dual_fusable(a_in, b_in), "gemm dual: the two problems do not share an instantiation");
+  GemmParams q[2] = {a_in, b_in};
+  for (GemmParams& p : q) {
+    M3_REQUIRE((p.lda & 3) == 0, "gemm: lda=%d must be a multiple of 4", p.lda);
+    M3_REQUIRE(!(p.act == ACT_GLU) || (p.N & 1) == 0, "gemm: GLU needs even N");
+    M3_REQUIRE(!(p.ln_wsum && p.mask_in) || p.ln_wbeta, "gemm: folded LayerNorm + input mask needs ln_wbeta");
+    if (p.ln_wsum) M3_REQUIRE(p.K <= 1024, "gemm: LayerNorm supports rows up to 1024 wide");
+    if (p.mask_in || p.mask_out) M3_REQUIRE(p.row_len && p.rows_per_batch > 0, "gemm: mask needs row_len");
+    const int Nout = p.act == ACT_GLU ? p.N / 2 : p.N;
+    p.n_tiles = cdiv(Nout, 16);
+    p.m_tiles = cdiv(p.M, 16);
+    p.xcd_swizzle = (p.n_tiles % 8 == 0) ? 1 : 0;
+  }
+  const GemmVariant v = gemm_f32_variant(a_in);
+  const int n0 = (int)align_up((size_t)q[0].n_tiles * q[0].m_tiles, 8);
+  dim3 grid(n0 + q[1].n_tiles * q[1].m_tiles);
+#define M3_DUAL(GLU_, NW_, LN_)                                                                                             \
+  hipLaunchKernelGGL((gemm_f32_dual_kernel<1, GLU_, NW_, LN_>), grid, dim3(64 * NW_), 0, stream, q[0], q[1], n0)
+  if (v.glu) {
+    if (v.nw == 8) { if (v.ln == LN_EPI) M3_DUAL(true, 8, LN_EPI); else M3_DUAL(true, 8, LN_NONE); }
+    else { if (v.ln == LN_EPI) M3_DUAL(true, 4, LN_EPI); else M3_DUAL(true, 4, LN_NONE); }
+  } else {
+    if (v.nw == 8) { if (v.ln == LN_EPI) M3_DUAL(false, 8, LN_EPI); else M3_DUAL(false, 8, LN_NONE); }
+    else { if (v.ln == LN_EPI) M3_DUAL(false, 4, LN_EPI); else M3_DUAL(false, 4, LN_NONE); }
+  }
+#undef M3_DUAL
+  M3_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_gemm_f32(const GemmParams& pin, hipStream_t stream) {

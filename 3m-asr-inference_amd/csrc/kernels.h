@@ -52,7 +52,9 @@ struct GemmParams {
   // filled by launch_gemm_f32
   int n_tiles = 0, m_tiles = 0, xcd_swizzle = 0;
 };
-int launch_gemm_f32(const GemmParams& p, hipStream_t stream);   // dispatches to launch_gemm_bf16w when p.w_bf16
+int launch_gemm_f32(const GemmParams& p, hipStream_t stream);
+bool gemm_f32_dual_fusable(const GemmParams& a, const GemmParams& b);   // two independent skinny fp32 GEMMs of one instantiation
+int launch_gemm_f32_dual(const GemmParams& a, const GemmParams& b, hipStream_t stream);   // ... in ONE launch   // dispatches to launch_gemm_bf16w when p.w_bf16
 int launch_gemm_bf16w(const GemmParams& p, hipStream_t stream);
 const char* gemm_kernel_label(const GemmParams& p, bool splitk);   // the kernel these dispatchers will run (observability)
 bool gemm_bf16w_uses_tiled(const GemmParams& p);   // the choice launch_gemm_bf16w makes for this problem (sizes / mode only)

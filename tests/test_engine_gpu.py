@@ -105,10 +105,16 @@ def test_engine_forked_embed_branch_is_bit_identical(B, wdt):
         forked.forward(use_graph=True)
         forked.stream.synchronize()
         assert torch.equal(forked._bound[2], eager)
-    assert forked.workspace_size(B, T) > chain.workspace_size(B, T)   # the embed branch's scratch
+    # the embed branch's scratch (a single chain that interleaves the two encoders' GEMMs -- see `pairs` below -- has it too)
+    assert forked.workspace_size(B, T) >= chain.workspace_size(B, T)
     # the same kernels -- plus, on unpacked rows, the separate length kernel: in one chain the first conv1 forms the subsampled
     # lengths on its way, in a forked graph the main branch reads them while the embed branch's conv1 runs beside it
-    assert forked.num_kernels() - chain.num_kernels() == (0 if chain.packed_rows() else 1)
+    # (and, since round 4, minus the launches the single chain saves by running a GEMM of the embed encoder and one of the main
+    # encoder's first block as ONE launch -- stages named "a+b"; the forked plan has two streams for that)
+    pairs = sum("+" in n for n in chain.stage_names())
+    assert forked.num_kernels() - chain.num_kernels() == pairs + (0 if chain.packed_rows() else 1)
+    if B == 1 and wdt == "f32":
+        assert pairs >= 6, chain.stage_names()
 
 
 def test_fused_and_staged_route_paths_agree():
