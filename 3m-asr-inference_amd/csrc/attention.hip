@@ -19,15 +19,14 @@
 
 namespace m3 {
 
+// (the body as a device function of the work-group id: relpos_attention_dual_kernel runs two independent attention problems --
+//  the embed encoder's and the main encoder's first block, different head widths -- in one launch; engine.hip "horizontal fusion")
 template <int DK>
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, int ldq,
-                                                              const float* __restrict__ pmat, int ldp,
-                                                              const float* __restrict__ pos_u,
-                                                              const float* __restrict__ pos_v,
-                                                              const int32_t* __restrict__ row_len, int T, int D,
-                                                              float scale, float* __restrict__ out, int ldo, int out_bf16,
-                                                              const int32_t* __restrict__ row0, int QT, int H, int xcd_map,
-                                                              int chunk, int left_chunks) {
+__device__ __forceinline__ void relpos_attention_body(const float* __restrict__ qkv, int ldq, const float* __restrict__ pmat, int ldp,
+                                                      const float* __restrict__ pos_u, const float* __restrict__ pos_v,
+                                                      const int32_t* __restrict__ row_len, int T, int D, float scale,
+                                                      float* __restrict__ out, int ldo, int out_bf16, const int32_t* __restrict__ row0,
+                                                      int QT, int H, int xcd_map, int chunk, int left_chunks, const int wg_id) {
   constexpr int KS = DK / 16;
   // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~5 dependent s_load rounds otherwise)
   asm volatile("" ::"s"(qkv), "s"(ldq), "s"(pmat), "s"(ldp), "s"(pos_u), "s"(pos_v), "s"(row_len), "s"(T), "s"(D), "s"(scale),
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
   // only changes speed, never the result.
   int b, h, q0;
   {
-    const int id = blockIdx.x;
+    const int id = wg_id;
     int bh, qt;
     if (xcd_map) {
       const int g = id & 7, slot = id >> 3;
@@ -179,6 +178,66 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __re
     if (out_bf16) reinterpret_cast<bf16_t*>(out)[(brow + qrow) * ldo + h * DK + d] = (bf16_t)o;
     else out[(brow + qrow) * ldo + h * DK + d] = o;
   }
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const float* __restrict__ qkv, int ldq,
+                                                              const float* __restrict__ pmat, int ldp,
+                                                              const float* __restrict__ pos_u,
+                                                              const float* __restrict__ pos_v,
+                                                              const int32_t* __restrict__ row_len, int T, int D,
+                                                              float scale, float* __restrict__ out, int ldo, int out_bf16,
+                                                              const int32_t* __restrict__ row0, int QT, int H, int xcd_map,
+                                                              int chunk, int left_chunks) {
+  relpos_attention_body<DK>(qkv, ldq, pmat, ldp, pos_u, pos_v, row_len, T, D, scale, out, ldo, out_bf16, row0, QT, H, xcd_map, chunk,
+                            left_chunks, (int)blockIdx.x);
+}
+struct AttKernArgs {
+  const float *qkv; int ldq; const float* pmat; int ldp; const float *pos_u, *pos_v; const int32_t* row_len; int T, D; float scale;
+  float* out; int ldo, out_bf16; const int32_t* row0; int QT, H, xcd_map, chunk, left_chunks, n_wg;
+};
+// work-groups [0, n0) the first problem (n0 = its count rounded up to a multiple of 8: "id % 8 = XCD" holds for both), the rest the second
+template <int DK0, int DK1>
+__global__ __launch_bounds__(256) void relpos_attention_dual_kernel(const AttKernArgs a, const AttKernArgs b, const int n0) {
+  if ((int)blockIdx.x < n0) {
+    if ((int)blockIdx.x < a.n_wg)
+      relpos_attention_body<DK0>(a.qkv, a.ldq, a.pmat, a.ldp, a.pos_u, a.pos_v, a.row_len, a.T, a.D, a.scale, a.out, a.ldo, a.out_bf16, a.row0,
+                                 a.QT, a.H, a.xcd_map, a.chunk, a.left_chunks, (int)blockIdx.x);
+  } else {
+    relpos_attention_body<DK1>(b.qkv, b.ldq, b.pmat, b.ldp, b.pos_u, b.pos_v, b.row_len, b.T, b.D, b.scale, b.out, b.ldo, b.out_bf16, b.row0,
+                               b.QT, b.H, b.xcd_map, b.chunk, b.left_chunks, (int)blockIdx.x - n0);
+  }
+}
+
+int launch_relpos_attention_args(const AttArgs& a, hipStream_t stream) {
+  return launch_relpos_attention(a.qkv, a.ldq, a.pmat, a.ldp, a.pos_u, a.pos_v, a.row_len, a.B, a.T, a.H, a.dk, a.scale, a.out, a.ldo, stream,
+                                 a.out_bf16, a.row0, a.chunk, a.left_chunks);
+}
+static bool att_dual_dk(int dk) { return dk == 64 || dk == 128; }
+bool relpos_attention_dual_fusable(const AttArgs& a, const AttArgs& b) {
+  return att_dual_dk(a.dk) && att_dual_dk(b.dk) && a.B > 0 && a.T > 0 && b.B > 0 && b.T > 0 && (a.ldq & 3) == 0 && (a.ldp & 3) == 0 &&
+         (b.ldq & 3) == 0 && (b.ldp & 3) == 0;
+}
+int launch_relpos_attention_dual(const AttArgs& a, const AttArgs& b, hipStream_t stream) {
+  M3_REQUIRE(relpos_attention_dual_fusable(a, b), "attention dual: head widths %d / %d are not a dual instantiation", a.dk, b.dk);
+  auto pack = [](const AttArgs& q) {
+    AttKernArgs k;
+    k.qkv = q.qkv; k.ldq = q.ldq; k.pmat = q.pmat; k.ldp = q.ldp; k.pos_u = q.pos_u; k.pos_v = q.pos_v; k.row_len = q.row_len; k.T = q.T;
+    k.D = q.H * q.dk; k.scale = q.scale; k.out = q.out; k.ldo = q.ldo; k.out_bf16 = q.out_bf16; k.row0 = q.row0; k.QT = cdiv(q.T, 16); k.H = q.H;
+    k.xcd_map = ((q.H * q.B) % 8 == 0) ? 1 : 0; k.chunk = q.chunk; k.left_chunks = q.left_chunks; k.n_wg = k.QT * q.H * q.B;
+    return k;
+  };
+  const AttKernArgs ka = pack(a), kb = pack(b);
+  const int n0 = (int)align_up((size_t)ka.n_wg, 8);
+  dim3 grid(n0 + kb.n_wg);
+#define M3_ATTD(D0_, D1_) hipLaunchKernelGGL((relpos_attention_dual_kernel<D0_, D1_>), grid, dim3(256), 0, stream, ka, kb, n0)
+  if (a.dk == 128 && b.dk == 64) M3_ATTD(128, 64);
+  else if (a.dk == 64 && b.dk == 128) M3_ATTD(64, 128);
+  else if (a.dk == 64) M3_ATTD(64, 64);
+  else M3_ATTD(128, 128);
+#undef M3_ATTD
+  M3_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,

@@ -36,20 +36,19 @@ struct DwCausal {
 
 // CAUSAL is a template parameter: the symmetric form is the round-3 kernel instruction for instruction (making it a run-time
 // field of one kernel cost 4.9 -> 8.3 us per launch at B = 1: a pointer select in front of every tap load).
+// (the body as a device function of the work-group's row: dwconv_ln_silu_dual_kernel runs two independent problems in one launch,
+//  see gemm.hip / engine.hip "horizontal fusion")
 template <int KT, bool CAUSAL>
-__global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
-                                                              const float* __restrict__ bias,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float eps, int T,
-                                                              int D, int K, float* __restrict__ out, int out_bf16,
-                                                              const int32_t* __restrict__ pad_of,
-                                                              const int32_t* __restrict__ row0,
-                                                              const int32_t* __restrict__ row_len, int n_rows, DwCausal cs) {
+__device__ __forceinline__ void dwconv_ln_silu_body(const float* __restrict__ z, const float* __restrict__ w_kc,
+                                                    const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, int T, int D, int K,
+                                                    float* __restrict__ out, int out_bf16, const int32_t* __restrict__ pad_of,
+                                                    const int32_t* __restrict__ row0, const int32_t* __restrict__ row_len,
+                                                    int n_rows, const DwCausal& cs, const int row) {
   __shared__ float red[2][16];
   // one batch of kernel-argument loads instead of one per first use (see gemm.hip: ~6 dependent s_load rounds otherwise)
   asm volatile("" ::"s"(z), "s"(w_kc), "s"(bias), "s"(gamma), "s"(beta), "s"(eps), "s"(T), "s"(D), "s"(K), "s"(out), "s"(out_bf16),
                "s"(pad_of), "s"(row0), "s"(row_len), "s"(n_rows));
-  const int row = blockIdx.x;
   const int c = threadIdx.x * 4;
   const bool live = c < D;
   const float* leftp = cs.left;
@@ -154,6 +153,31 @@ __global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __res
   }
 }
 
+template <int KT, bool CAUSAL>
+__global__ __launch_bounds__(1024) void dwconv_ln_silu_kernel(const float* __restrict__ z, const float* __restrict__ w_kc,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, int T,
+                                                              int D, int K, float* __restrict__ out, int out_bf16,
+                                                              const int32_t* __restrict__ pad_of,
+                                                              const int32_t* __restrict__ row0,
+                                                              const int32_t* __restrict__ row_len, int n_rows, DwCausal cs) {
+  dwconv_ln_silu_body<KT, CAUSAL>(z, w_kc, bias, gamma, beta, eps, T, D, K, out, out_bf16, pad_of, row0, row_len, n_rows, cs, (int)blockIdx.x);
+}
+struct DwKernArgs {
+  const float *z, *w_kc, *bias, *gamma, *beta; float eps; int T, D, K; float* out; int out_bf16;
+  const int32_t *pad_of, *row0, *row_len; int n_rows; DwCausal cs;
+};
+template <int KT, bool CAUSAL>
+__global__ __launch_bounds__(1024) void dwconv_ln_silu_dual_kernel(const DwKernArgs a, const DwKernArgs b) {
+  if ((int)blockIdx.x < a.n_rows)
+    dwconv_ln_silu_body<KT, CAUSAL>(a.z, a.w_kc, a.bias, a.gamma, a.beta, a.eps, a.T, a.D, a.K, a.out, a.out_bf16, a.pad_of, a.row0, a.row_len,
+                                    a.n_rows, a.cs, (int)blockIdx.x);
+  else
+    dwconv_ln_silu_body<KT, CAUSAL>(b.z, b.w_kc, b.bias, b.gamma, b.beta, b.eps, b.T, b.D, b.K, b.out, b.out_bf16, b.pad_of, b.row0, b.row_len,
+                                    b.n_rows, b.cs, (int)blockIdx.x - a.n_rows);
+}
+
 static int launch_dwconv_impl(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta, float eps,
                               int B, int T, int D, int K, float* out, hipStream_t stream, int out_bf16, const int32_t* pad_of,
                               const int32_t* row0, const int32_t* row_len, const DwCausal& cs) {
@@ -180,6 +204,35 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
   DwCausal cs;
   if (causal_left_fill != nullptr) { cs.causal = 1; cs.left = causal_left_fill; }
   return launch_dwconv_impl(z, w_kc, bias, gamma, beta, eps, B, T, D, K, out, stream, out_bf16, pad_of, row0, row_len, cs);
+}
+
+int launch_dwconv_ln_silu_args(const DwArgs& a, hipStream_t stream) {
+  return launch_dwconv_ln_silu(a.z, a.w_kc, a.bias, a.gamma, a.beta, a.eps, a.B, a.T, a.D, a.K, a.out, stream, a.out_bf16, a.pad_of, a.row0,
+                               a.row_len, a.causal_left_fill);
+}
+// two independent conv modules of the same shape class (channels, taps, causal or not) in ONE launch
+bool dwconv_dual_fusable(const DwArgs& a, const DwArgs& b) {
+  return a.D == b.D && a.K == b.K && (a.causal_left_fill != nullptr) == (b.causal_left_fill != nullptr) && a.B * a.T > 0 && b.B * b.T > 0 &&
+         (a.D & 3) == 0 && a.D <= 4096 && (a.causal_left_fill != nullptr || (a.K & 1) == 1);
+}
+int launch_dwconv_ln_silu_dual(const DwArgs& a, const DwArgs& b, hipStream_t stream) {
+  M3_REQUIRE(dwconv_dual_fusable(a, b), "dwconv dual: the two problems do not share an instantiation");
+  auto pack = [](const DwArgs& q) {
+    DwKernArgs k;
+    k.z = q.z; k.w_kc = q.w_kc; k.bias = q.bias; k.gamma = q.gamma; k.beta = q.beta; k.eps = q.eps; k.T = q.T; k.D = q.D; k.K = q.K;
+    k.out = q.out; k.out_bf16 = q.out_bf16; k.pad_of = q.pad_of; k.row0 = q.row0; k.row_len = q.row_len; k.n_rows = q.B * q.T;
+    if (q.causal_left_fill != nullptr) { k.cs.causal = 1; k.cs.left = q.causal_left_fill; }
+    return k;
+  };
+  const DwKernArgs ka = pack(a), kb = pack(b);
+  const int threads = (int)align_up(a.D / 4, 64), grid = ka.n_rows + kb.n_rows;
+  const bool causal = a.causal_left_fill != nullptr;
+#define M3_DWD_CASE(KT_, C_) hipLaunchKernelGGL((dwconv_ln_silu_dual_kernel<KT_, C_>), dim3(grid), dim3(threads), 0, stream, ka, kb)
+  if (a.K <= 15) { if (causal) M3_DWD_CASE(15, true); else M3_DWD_CASE(15, false); }
+  else { if (causal) M3_DWD_CASE(8, true); else M3_DWD_CASE(8, false); }
+#undef M3_DWD_CASE
+  M3_LAUNCH_CHECK();
+  return 0;
 }
 
 // chunk-by-chunk (streaming) form of the causal conv: cache_pair [2][B][K-1][D], chunk counter and valid frames on the device

@@ -57,8 +57,12 @@ struct Stage {
   std::string name;
   std::function<int(hipStream_t)> run;
   m3_stage_info info;   // kernel label + algorithmic bytes / FLOPs of the stage (m3_engine_stage_info)
-  bool is_gemm = false; // a plain launch_gemm_f32 stage: `gemm` holds its problem (what horizontal fusion pairs up)
+  // what horizontal fusion pairs up (fuse_independent_pairs): 1 = a plain launch_gemm_f32 stage (`gemm`), 2 = the conv module's
+  // depthwise conv + LayerNorm + SiLU (`dw`)
+  int fuse_kind = 0;
   GemmParams gemm;
+  DwArgs dw;
+  AttArgs att;          // 3 = the fp32 rel-pos attention core
 };
 
 m3_stage_info stage_info(const char* kernel, int launches, double bytes, double flops, bool per_row = true) {
@@ -483,7 +487,7 @@ static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool f
     return;
   }
   add_stage(e, name, 1, [p](hipStream_t s) { return launch_gemm_f32(p, s); }, gemm_info(p, false));
-  e->cur.stages.back().is_gemm = true;
+  e->cur.stages.back().fuse_kind = 1;
   e->cur.stages.back().gemm = p;
 }
 
@@ -493,7 +497,34 @@ static void add_gemm(m3_engine* e, const std::string& name, GemmParams p, bool f
 // 275 dependent launches.  Each chain keeps its own order; only the first embed stage (it also derives the output lengths every
 // later kernel reads) is guaranteed to stay in front of every main-prefix stage.  Arithmetic per problem is unchanged: results
 // are bit-identical.  M3_HFUSE=0: off.
-static void fuse_independent_gemm_pairs(m3_engine* e, int first, int mid, int join) {
+static bool stages_fusable(const Stage& a, const Stage& b) {
+  if (a.fuse_kind == 0 || a.fuse_kind != b.fuse_kind) return false;
+  if (a.fuse_kind == 1) return gemm_f32_dual_fusable(a.gemm, b.gemm);
+  if (a.fuse_kind == 2) return dwconv_dual_fusable(a.dw, b.dw);
+  if (a.fuse_kind == 3) return relpos_attention_dual_fusable(a.att, b.att);
+  return false;
+}
+static Stage fused_stage(const Stage& a, const Stage& b) {
+  Stage d;
+  d.name = a.name + "+" + b.name;
+  const char* label = "";
+  if (a.fuse_kind == 1) {
+    const GemmParams pa = a.gemm, pb = b.gemm;
+    d.run = [pa, pb](hipStream_t s) { return launch_gemm_f32_dual(pa, pb, s); };
+    label = "gemm_f32_dual_kernel";
+  } else if (a.fuse_kind == 2) {
+    const DwArgs pa = a.dw, pb = b.dw;
+    d.run = [pa, pb](hipStream_t s) { return launch_dwconv_ln_silu_dual(pa, pb, s); };
+    label = "dwconv_ln_silu_dual_kernel";
+  } else {
+    const AttArgs pa = a.att, pb = b.att;
+    d.run = [pa, pb](hipStream_t s) { return launch_relpos_attention_dual(pa, pb, s); };
+    label = "relpos_attention_dual_kernel";
+  }
+  d.info = stage_info(label, 1, a.info.alg_bytes + b.info.alg_bytes, a.info.flops + b.info.flops);
+  return d;
+}
+static void fuse_independent_pairs(m3_engine* e, int first, int mid, int join) {
   if (first < 0 || mid <= first + 1 || join <= mid) return;
   std::vector<Stage>& st = e->cur.stages;
   std::vector<Stage> out(st.begin(), st.begin() + first);
@@ -501,19 +532,14 @@ static void fuse_independent_gemm_pairs(m3_engine* e, int first, int mid, int jo
   int i = first, saved = 0;
   for (int m = mid; m < join; ++m) {
     int partner = -1;
-    if (st[m].is_gemm)
+    if (st[m].fuse_kind)
       for (int k = std::max(i, first + 1); k < mid; ++k)
-        if (st[k].is_gemm && gemm_f32_dual_fusable(st[k].gemm, st[m].gemm)) { partner = k; break; }
+        if (stages_fusable(st[k], st[m])) { partner = k; break; }
     if (partner < 0) { pending.push_back(st[m]); continue; }
     for (; i < partner; ++i) out.push_back(st[i]);
     for (Stage& q : pending) out.push_back(q);
     pending.clear();
-    const GemmParams a = st[partner].gemm, b = st[m].gemm;
-    Stage d;
-    d.name = st[partner].name + "+" + st[m].name;
-    d.run = [a, b](hipStream_t s) { return launch_gemm_f32_dual(a, b, s); };
-    d.info = stage_info("gemm_f32_dual_kernel", 1, st[partner].info.alg_bytes + st[m].info.alg_bytes, st[partner].info.flops + st[m].info.flops);
-    out.push_back(d);
+    out.push_back(fused_stage(st[partner], st[m]));
     i = partner + 1;
     ++saved;
   }
@@ -646,11 +672,20 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         return launch_relpos_attention_stream(qkv, 3 * D, hist, cap, pmat, ldp, pu, pv, lens, step, B, Tp, H, dk, scale, ctx, D, left_chunks, s);
       }, stage_info("relpos_attention_stream_kernel", 1, (double)S * D * 24 + (double)Tp * D * 4, 6.0 * Tp * D * S));
     } else
+    {
     add_stage(e, pfx + "att.core", 1, [=](hipStream_t s) {
       if (att16) return launch_relpos_attention_bf16(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, row0, chunk, left_chunks);
       return launch_relpos_attention(qkv, 3 * D, pmat, ldp, pu, pv, lens, B, Tp, H, dk, scale, ctx, D, s, a16, row0, chunk, left_chunks);
     }, stage_info(att16 ? "relpos_attention_bf16_kernel" : "relpos_attention_kernel", 1,
                   (double)S * D * (att16 ? 8 : (12 + (a16 ? 2 : 4))) + (double)Tp * D * 4, 6.0 * Tp * D * S));
+    if (!att16) {      // (the fp32 core: a candidate for sharing a launch with the other encoder's, fuse_independent_pairs)
+      AttArgs aa;
+      aa.qkv = qkv; aa.ldq = 3 * D; aa.pmat = pmat; aa.ldp = ldp; aa.pos_u = pu; aa.pos_v = pv; aa.row_len = lens; aa.B = B; aa.T = Tp; aa.H = H;
+      aa.dk = dk; aa.scale = scale; aa.out = ctx; aa.ldo = D; aa.out_bf16 = a16; aa.row0 = row0; aa.chunk = chunk; aa.left_chunks = left_chunks;
+      e->cur.stages.back().fuse_kind = 3;
+      e->cur.stages.back().att = aa;
+    }
+    }
     GemmParams o;
     o.A = pl.ctx; o.lda = D; o.W = w.out.w; o.bias = w.out.b; o.Y = x; o.ldy = D; o.M = S; o.N = D; o.K = D;
     o.resid = x; o.ldr = D;
@@ -677,9 +712,15 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
         return launch_dwconv_ln_silu_stream(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, cpair, step, lens, s, a16);
       }, stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * 8 + (double)K * D * 4 + 8.0 * B * (K - 1) * D, 2.0 * K * D * S));
     } else
-    add_stage(e, pfx + "conv.dw_ln_silu", 1, [=](hipStream_t s) {
-      return launch_dwconv_ln_silu(glu, dww, dwb, ng, nb, 1e-5f, B, Tp, D, K, dw, s, a16, pad_of, row0, lens, lfill);
-    }, stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * (4 + (a16 ? 2 : 4)) + (double)K * D * 4, 2.0 * K * D * S));
+    {
+      DwArgs da;
+      da.z = glu; da.w_kc = dww; da.bias = dwb; da.gamma = ng; da.beta = nb; da.eps = 1e-5f; da.B = B; da.T = Tp; da.D = D; da.K = K;
+      da.out = dw; da.out_bf16 = a16; da.pad_of = pad_of; da.row0 = row0; da.row_len = lens; da.causal_left_fill = lfill;
+      add_stage(e, pfx + "conv.dw_ln_silu", 1, [da](hipStream_t s) { return launch_dwconv_ln_silu_args(da, s); },
+                stage_info("dwconv_ln_silu_kernel", 1, (double)S * D * (4 + (a16 ? 2 : 4)) + (double)K * D * 4, 2.0 * K * D * S));
+      e->cur.stages.back().fuse_kind = 2;
+      e->cur.stages.back().dw = da;
+    }
     GemmParams h;
     h.A = pl.dw; h.lda = D; h.W = w.pw2.w; h.bias = w.pw2.b; h.Y = x; h.ldy = D; h.M = S; h.N = D; h.K = D;
     h.row_len = live_len; h.rows_per_batch = live_rpb; h.mask_out = 1; h.resid = x; h.ldr = D;
@@ -1242,7 +1283,7 @@ static int prepare_impl(m3_engine* e, const float* feat, const int32_t* feat_len
       const std::string& n = e->cur.stages[i].name;
       if (n == "blocks.0.moe_router" || n == "blocks.0.moe_route" || n == "blocks.0.moe_gate_index") { join = (int)i; break; }
     }
-    if (join > 0) fuse_independent_gemm_pairs(e, hf_first, hf_mid, join);
+    if (join > 0) fuse_independent_pairs(e, hf_first, hf_mid, join);
   }
   if (streaming) {   // the chunk counter moves on the device: the same captured graph serves every chunk of the stream
     int32_t* step = carve_stream_state(c, sstate, B, s_hist).step;

@@ -218,7 +218,16 @@ int launch_bmm(const float* a, const float* b, float* c, int batch, int M, int N
 int launch_relpos_attention(const float* qkv, int ldq, const float* pmat, int ldp, const float* pos_u,
                             const float* pos_v, const int32_t* row_len, int B, int T, int H, int dk, float scale,
                             float* out, int ldo, hipStream_t stream, int out_bf16 = 0, const int32_t* row0 = nullptr,
-                            int chunk = 0, int left_chunks = -1);   // chunk > 0: static chunk mask (utils/mask.py:42-75)
+                            int chunk = 0, int left_chunks = -1);
+// the same as a value (what the engine keeps per stage so that two independent attention stages can share a launch)
+struct AttArgs {
+  const float* qkv = nullptr; int ldq = 0; const float* pmat = nullptr; int ldp = 0; const float *pos_u = nullptr, *pos_v = nullptr;
+  const int32_t* row_len = nullptr; int B = 0, T = 0, H = 0, dk = 0; float scale = 1.f; float* out = nullptr; int ldo = 0, out_bf16 = 0;
+  const int32_t* row0 = nullptr; int chunk = 0, left_chunks = 0;
+};
+int launch_relpos_attention_args(const AttArgs& a, hipStream_t stream);
+bool relpos_attention_dual_fusable(const AttArgs& a, const AttArgs& b);
+int launch_relpos_attention_dual(const AttArgs& a, const AttArgs& b, hipStream_t stream);   // chunk > 0: static chunk mask (utils/mask.py:42-75)
 // chunk-by-chunk form: C query frames per utterance, K / V history [B][cap][2D] appended to in place, device-side chunk counter
 int launch_relpos_attention_stream(const float* qkv, int ldq, float* hist, int cap, const float* pmat, int ldp, const float* pos_u,
                                    const float* pos_v, const int32_t* chunk_len, const int32_t* step, int B, int C, int H, int dk,
@@ -239,6 +248,15 @@ int launch_dwconv_ln_silu(const float* z, const float* w_kc, const float* bias, 
 int launch_pad2d(const float* x, size_t outer, int H, int W, int pre_h, int post_h, int pre_w, int post_w, float* y, hipStream_t stream);
 int launch_advance_counter(int32_t* counter, int by, hipStream_t stream);
 int launch_fill_rows(const float* row, int D, float* out, size_t rows, hipStream_t stream);
+// the same as a value (what the engine keeps per stage so that two independent conv modules can share a launch)
+struct DwArgs {
+  const float *z = nullptr, *w_kc = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr; float eps = 1e-5f;
+  int B = 0, T = 0, D = 0, K = 0; float* out = nullptr; int out_bf16 = 0;
+  const int32_t *pad_of = nullptr, *row0 = nullptr, *row_len = nullptr; const float* causal_left_fill = nullptr;
+};
+int launch_dwconv_ln_silu_args(const DwArgs& a, hipStream_t stream);
+bool dwconv_dual_fusable(const DwArgs& a, const DwArgs& b);
+int launch_dwconv_ln_silu_dual(const DwArgs& a, const DwArgs& b, hipStream_t stream);
 int launch_dwconv_ln_silu_stream(const float* z, const float* w_kc, const float* bias, const float* gamma, const float* beta,
                                  float eps, int B, int T, int D, int K, float* out, float* cache_pair, const int32_t* step,
                                  const int32_t* chunk_len, hipStream_t stream, int out_bf16 = 0);
