@@ -770,6 +770,7 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const bool split_route = c.fuse_route == 2 && world == 1 && S < 1024 && (Etot == 8 || Etot == 16 || Etot == 32 || Etot == 64);
     bool router_gate = false;   // the dedicated router kernel also did SoftmaxTopK (no moe_top1 stage)
     bool use_xq = false;        // ... and left the rows quantised for the fused fp8 expert kernel
+    bool split_self = false;    // split route whose expert launch routes for itself (slabs hold ORIGINAL rows, b2 inside)
     int32_t* fs_dev = nullptr;  // the fused fp8 kernel's device-side F split (slab count), when it is allowed to choose
     if (split_route) {
       GemmParams r;
@@ -777,12 +778,21 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
       r.Y = rl; r.ldy = Etot; r.M = S; r.N = Etot; r.K = D;
       r.resid = pl.eall + (size_t)layer * E; r.ldr = c.num_blocks * E;
       add_gemm(e, pfx + "moe_router", r, true);
+      // (the expert launch routes for itself here too: no index launch; M3_SELF_ROUTE=0 puts it back)
+      split_self = self_route_enabled() && c.weight_dtype == M3_F32 && expert_ffn_f32_self_routing(S, Etot) && !expert_ffn_f32_tiled(S, E, D, F);
+      if (split_self) {
+        add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
+          return launch_expert_route_ffn_f32(x, D, rl, live_len, live_rpb, S, E, D, F, ew1, eb1, ew2, 1, eb2, mw.slab, gidx, gval,
+                                             mw.mapping, mw.acc, mw.pos, s, ng, nb, eps);
+        }, stage_info("expert_ffn_f32_kernel", 1, -1.0, 4.0 * D * F * S));
+      } else {
       add_stage(e, pfx + "moe_gate_index", 1, [=](hipStream_t s) {
         return launch_moe_gate_index(rl, Etot, live_len, live_rpb, S, gidx, gval, mw.mapping, mw.acc, mw.pos, s);
       }, stage_info("moe_index_kernel", 1, (double)S * (Etot * 4 + 16) + 4.0 * (E + 1), 0.0));
       add_stage(e, pfx + "moe_local.expert", 1, [=](hipStream_t s) {
         return launch_expert_ffn_f32(x, D, mw.pos, mw.acc, S, E, D, F, ew1, eb1, ew2, 1, mw.slab, ng, nb, eps, s);
       }, stage_info("expert_ffn_f32_kernel", 1, -1.0, 4.0 * D * F * S));
+      }
     } else if (fused_route) {
       // router (x half, norm_ff folded; embed half precomputed for all layers by "router_e_all") + SoftmaxTopK +
       // ScatterMapping in ONE launch; the expert kernel applies norm_ff itself while it gathers rows
@@ -951,8 +961,8 @@ static void build_block(m3_engine* e, const std::string& pfx, const BlockW& w, i
     const float* erows = (fused_route || split_route) ? mw.slab : (e16c ? expert_ffn_w16_rows(wmode_c, mw.slab, S, E, D, F) : expert_ffn_f32_rows(mw.slab, S, E, D, F));
     const int eslices = (fused_route || split_route) ? F / kExpertSlice : (e16c ? expert_ffn_w16_slices(wmode_c, S, E, D, F) : expert_ffn_f32_slices(S, E, D, F));
     // (self-routing expert launch: slabs hold ORIGINAL rows with b2 already in slice 0 -> no mapping, no b2 here)
-    const int32_t* cmap = self_route ? nullptr : mw.mapping;
-    const float* cb2 = self_route ? nullptr : eb2;
+    const int32_t* cmap = (self_route || split_self) ? nullptr : mw.mapping;
+    const float* cb2 = (self_route || split_self) ? nullptr : eb2;
     add_stage(e, pfx + "moe_local.combine", 1, [=](hipStream_t s) {
       return launch_moe_combine(erows, fs_dev ? 4 : eslices, cmap, gidx, gv, cb2, x, 0.5f, fg, fb, eps, x, S, D, s, a16 ? xb : nullptr,
                                 dma ? xstats : nullptr, fs_dev);

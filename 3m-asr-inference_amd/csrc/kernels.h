@@ -174,7 +174,7 @@ bool expert_ffn_f32_self_routing(int S, int E);
 int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, const int32_t* row_len, int rows_per_batch, int S, int E,
                                 int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, const float* b2,
                                 float* slab, int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
-                                hipStream_t stream);
+                                hipStream_t stream, const float* ln_gamma = nullptr, const float* ln_beta = nullptr, float ln_eps = 0.f);
 // grouped bf16 expert GEMMs on 256 x 256 x 64 LDS-DMA tiles (expert_gemm_g256.hip): saturating row counts (>= 512 rows per expert)
 bool expert_ffn_bf16_g256(int S, int E, int D, int F);
 int init_expert_gemm_g256_kernels();

@@ -364,7 +364,9 @@ bool expert_ffn_f32_self_routing(int S, int E) { return S >= 1 && S <= 64 * (kEx
 int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, const int32_t* row_len, int rows_per_batch, int S, int E,
                                 int D, int F, const float* w1, const float* b1, const float* w2, int w2_sliced, const float* b2,
                                 float* slab, int32_t* gate_idx, float* gate_value, int32_t* mapping, int32_t* acc_hist, int32_t* pos,
-                                hipStream_t stream) {
+                                hipStream_t stream, const float* ln_gamma, const float* ln_beta, float ln_eps) {
+  // ln_gamma != null: x is the RAW residual stream and the layer's LayerNorm is applied while the rows are gathered (the split-route
+  // engines: the normalised MoE input is never written)
   M3_REQUIRE(expert_ffn_f32_self_routing(S, E), "expert_route_ffn: needs 1 <= S <= %d rows and 8/16/32/64 experts (S=%d E=%d)", 64 * (kExpertSlice / 16), S, E);
   M3_REQUIRE((D & 15) == 0 && D <= 2048 && F % kExpertSlice == 0 && (ldx & 3) == 0, "expert_route_ffn: bad dims D=%d F=%d ldx=%d", D, F, ldx);
   M3_REQUIRE(logits && gate_idx && gate_value && slab, "expert_route_ffn: null pointer");
@@ -374,7 +376,9 @@ int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, co
   M3_REQUIRE(lds_bytes <= 150 * 1024, "expert_route_ffn: LDS tile of %zu bytes does not fit", lds_bytes);
   static PerDeviceOnce once;
   if (!once.done()) {
-#define M3_ROUTE_ATTR(MT_, E_) M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<MT_, false, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+#define M3_ROUTE_ATTR(MT_, E_)                                                                                                                            \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<MT_, false, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+  M3_CHECK_HIP(hipFuncSetAttribute((const void*)expert_ffn_f32_kernel<MT_, true, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
     M3_ROUTE_ATTR(2, 8); M3_ROUTE_ATTR(2, 16); M3_ROUTE_ATTR(2, 32); M3_ROUTE_ATTR(2, 64);
 #undef M3_ROUTE_ATTR
     once.mark();
@@ -386,8 +390,14 @@ int launch_expert_route_ffn_f32(const float* x, int ldx, const float* logits, co
   const int w2_row_stride = w2_sliced ? kExpertSlice : F;
   const int w2_slice_stride = w2_sliced ? D * kExpertSlice : kExpertSlice;
 #define M3_ROUTE_CASE(MT_, E_)                                                                                              \
-  hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_, false, E_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, \
-                     nullptr, nullptr, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab, nullptr, nullptr, 0.f, rt)
+  do {                                                                                                                      \
+    if (ln_gamma != nullptr)                                                                                                \
+      hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_, true, E_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, \
+                         nullptr, nullptr, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab, ln_gamma, ln_beta, ln_eps, rt); \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((expert_ffn_f32_kernel<MT_, false, E_>), grid, dim3(64 * (kExpertSlice / 16)), lds_bytes, stream, x, ldx, \
+                         nullptr, nullptr, S, D, F, w1, b1, w2, w2_row_stride, w2_slice_stride, slab, nullptr, nullptr, 0.f, rt); \
+  } while (0)
 #define M3_ROUTE_E(E_) do { if (mt == 1) M3_ROUTE_CASE(1, E_); else M3_ROUTE_CASE(2, E_); } while (0)
   switch (E) {
     case 8: M3_ROUTE_E(8); break;
